@@ -1,0 +1,185 @@
+/* ptcore.h — C ABI of libptcore.so, the MI355X (gfx950) path-tracing core.
+ *
+ * The reference (ReinierMaas/PathTracer, Rust, /root/reference) has no FFI or plugin
+ * boundary; the seam replaced here is the per-pixel pair of calls in its frame loop,
+ *     camera.generate(x, y)  ->  camera.sample(&mut ray, 32)      src/main.rs:157-159
+ * plus accumulate + tonemap (src/main.rs:159-164), hoisted from per-pixel to per-frame,
+ * and (secondary, for bit-exact checks) BVH::intersect_closest / intersect_any
+ * (src/bvh.rs:180,227).  Each entry point below names the reference code it stands in for.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; all structs are POD, little-endian, fp32.
+ *  - every call returns PT_OK (0) or a negative pt_status; pt_last_error(ctx) gives text.
+ *    Nothing throws or aborts across the boundary (the reference panics instead).
+ *  - input arrays are caller-owned host memory and are copied during the call;
+ *    output arrays are caller-allocated host memory.
+ *  - a context is bound to one HIP device and is externally synchronised (one thread at a
+ *    time); distinct contexts are independent.  Calls are synchronous at return.
+ *  - there is NO CPU fallback: pt_create fails with PT_ERR_NO_DEVICE when no gfx950
+ *    device is usable.
+ *  - primitive ids are ORIGINAL object indices (the value stored in bvh.indices[i],
+ *    src/bvh.rs:200), independent of the flattened order on the device.
+ */
+#ifndef PTCORE_H
+#define PTCORE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pt_ctx pt_ctx;
+
+typedef enum pt_status {
+    PT_OK = 0,
+    PT_ERR_INVALID = -1,   /* bad argument (null pointer, zero size, wrong primitive kind ...) */
+    PT_ERR_STATE = -2,     /* call order violated (render before build / set_camera ...) */
+    PT_ERR_NO_DEVICE = -3, /* no usable HIP device / device index out of range */
+    PT_ERR_HIP = -4,       /* a HIP runtime call failed (text in pt_last_error) */
+    PT_ERR_LIMIT = -5,     /* scene exceeds a documented limit */
+    PT_ERR_BVH = -6        /* builder hit the empty-child hazard of src/bvh.rs:87-97 */
+} pt_status;
+
+/* Material — src/material.rs:5-18 (enum Material). */
+enum { PT_MAT_DIFFUSE = 0, PT_MAT_DIELECTRIC = 1, PT_MAT_EMISSIVE = 2 };
+typedef struct pt_material {
+    uint32_t kind; /* PT_MAT_* */
+    float a;       /* Diffuse: speculaty        Dielectric: refraction_index_n1 */
+    float b;       /* Diffuse: unused           Dielectric: refraction_index_n2 */
+    float rgb[3];  /* color */
+} pt_material;
+
+/* Ray — src/ray.rs:14-18 (origin, direction, distance). */
+typedef struct pt_ray {
+    float o[3];
+    float d[3];
+    float tmax;
+} pt_ray;
+
+/* Result of one traversal: the fields of Option<Intersection> (src/ray.rs:6-11) that identify
+ * the hit, plus ray.distance after the call.  prim == PT_MISS for None. */
+#define PT_MISS 0xFFFFFFFFu
+typedef struct pt_hit {
+    uint32_t prim;
+    float t;         /* ray.distance after the call (unchanged tmax on a miss) */
+    uint32_t inside; /* Intersection::inside */
+} pt_hit;
+
+/* One BVH node exactly as src/bvh.rs:10-14 (BVHNode: AABB + left_first + count), 32 bytes. */
+typedef struct pt_bvh_node {
+    float min[3];
+    uint32_t left_first;
+    float max[3];
+    uint32_t count;
+} pt_bvh_node;
+
+/* Camera state after Camera::update (src/camera.rs:271-292). */
+typedef struct pt_camera_state {
+    float origin[3], target[3], direction[3], right[3], up[3];
+    float p1[3], p2[3], p3[3];
+    float focal_distance, lens_size;
+    uint32_t width, height;
+} pt_camera_state;
+
+/* Work split for multi-GPU frames (no counterpart in the reference, which is one process):
+ *  PT_SHARD_ALL     whole image, sample indices [sample_begin, sample_begin+spp)
+ *  PT_SHARD_TILES   only the tile x tile pixel tiles t (row-major tile index) with t % nranks == rank
+ * sample indices are global, so any split of [0, S) over ranks reproduces the 1-GPU samples. */
+enum { PT_SHARD_ALL = 0, PT_SHARD_TILES = 1 };
+typedef struct pt_shard {
+    uint32_t kind;
+    uint32_t rank, nranks;
+    uint32_t tile;          /* tile edge in pixels (multiple of 8), PT_SHARD_TILES only */
+    uint32_t sample_begin;  /* global index of the first sample this call renders */
+} pt_shard;
+
+typedef struct pt_counters {
+    uint64_t paths;          /* generate+sample pairs started */
+    uint64_t rays_closest;   /* intersect_closest traversals executed (incl. look-ahead, re-trace) */
+    uint64_t rays_any;       /* intersect_any traversals executed */
+    uint64_t node_tests;     /* AABB records tested: 1 (root) + 2 per internal node entered */
+    uint64_t prim_tests;     /* Primitive::intersect calls */
+    uint64_t extend_launches;
+    double extend_ms;        /* sum of HIP-event durations of the traversal kernel (timed mode) */
+    double render_ms;        /* HIP-event duration of all pt_render calls since reset */
+} pt_counters;
+
+/* flags for pt_render */
+enum {
+    PT_RENDER_DEFAULT = 0,
+    PT_RENDER_TIMED = 1,   /* bracket every traversal launch with HIP events (extend_ms) */
+    PT_RENDER_COUNT = 2    /* instrumented traversal: fill node_tests / prim_tests (slower) */
+};
+
+const char *pt_strerror(int status);
+const char *pt_last_error(const pt_ctx *ctx);
+
+/* lifetime — replaces process start-up in src/main.rs:76-111 (no SDL). */
+int pt_create(int device, pt_ctx **out);
+void pt_destroy(pt_ctx *ctx);
+
+/* scene input — replaces Vec<Triangle>/Vec<Sphere> handed to Scene::new (src/scene.rs:26-33).
+ * A scene holds ONE primitive kind, like Scene<T: Primitive>.
+ *  pos/nrm: N x 9 floats (position0..2 / normal0..2, src/primitive/triangle.rs:14-22)
+ *  cr:      N x 4 floats (position.xyz, radius, src/primitive/sphere.rs:14-18) */
+int pt_set_triangles(pt_ctx *ctx, const float *pos, const float *nrm, const uint32_t *mat_id, uint64_t n);
+int pt_set_spheres(pt_ctx *ctx, const float *cr, const uint32_t *mat_id, uint64_t n);
+int pt_set_materials(pt_ctx *ctx, const pt_material *m, uint32_t count);
+/* skybox — replaces Scene::read_skybox (src/scene.rs:171-183): w x h x 3 floats, row-major.
+ * The device copy is zero-padded so the unclamped lookup of src/scene.rs:163-166 stays in
+ * range and reads black, as the reference's oversize Vec does (src/scene.rs:174). */
+int pt_set_sky(pt_ctx *ctx, const float *rgb, uint32_t w, uint32_t h);
+
+/* BVH::new (src/bvh.rs:25-179): CPU binned-SAH build, bit-identical tree and leaf order,
+ * then flattening + upload.  Also collects the lights list (src/bvh.rs:29-35). */
+int pt_build(pt_ctx *ctx);
+/* Adopt a tree the host built itself — the north-star arrangement, where the Rust host keeps
+ * BVH::new (src/bvh.rs:25-179) and hands over bvh_nodes + indices (src/bvh.rs:17-22).  The tree
+ * is validated (ranges, coverage, no sharing), flattened and uploaded; use instead of pt_build. */
+int pt_set_bvh(pt_ctx *ctx, const pt_bvh_node *nodes, uint64_t n_nodes, const uint64_t *indices, uint64_t n_indices);
+/* The same CPU build as pt_build with no context and no device: geom is N x 9 triangle
+ * positions (prim_kind 0) or N x 4 spheres (prim_kind 1).  nodes needs room for 2N-1 entries. */
+int pt_bvh_build(int prim_kind, const float *geom, uint64_t n, pt_bvh_node *nodes, uint64_t nodes_cap,
+                 uint64_t *indices, uint64_t *n_nodes_out, uint32_t *max_depth_out);
+/* read the tree back in the reference's own layout (parity of the build). */
+int pt_get_bvh_sizes(const pt_ctx *ctx, uint64_t *n_nodes, uint64_t *n_indices, uint32_t *max_depth);
+int pt_get_bvh(const pt_ctx *ctx, pt_bvh_node *nodes, uint64_t *indices);
+
+/* Camera::new + update + focus (src/camera.rs:89-112,214-292); the autofocus trace runs on
+ * the device.  Resets the accumulation, as src/main.rs:137-142 does on a camera change. */
+int pt_set_camera(pt_ctx *ctx, const float origin[3], const float target[3], uint32_t width,
+                  uint32_t height, float lens_size);
+int pt_get_camera(const pt_ctx *ctx, pt_camera_state *out);
+
+/* Camera::generate (src/camera.rs:426-449) for n pixels (xy: n x 2 u32) of global sample index
+ * `sample`; the four uniforms come from the counter-based stream of (seed, pixel, sample). */
+int pt_generate(pt_ctx *ctx, const uint32_t *xy, uint64_t n, uint32_t sample, uint64_t seed, pt_ray *rays);
+
+/* The frame loop body, src/main.rs:143-170: for each of `spp` samples, every pixel gets
+ * generate + sample(max_depth) added to the accumulator.  max_depth is the literal 32 of
+ * src/main.rs:159.  shard may be NULL (= PT_SHARD_ALL, sample_begin = samples rendered so far). */
+int pt_render(pt_ctx *ctx, uint32_t spp, uint32_t max_depth, uint64_t seed, const pt_shard *shard,
+              uint32_t flags);
+int pt_reset_accum(pt_ctx *ctx);
+/* accum: W x H x 3 floats, the running SUM (src/main.rs:100,159); spp_out: samples summed. */
+int pt_read_accum(pt_ctx *ctx, float *rgb, float *spp_out);
+/* vec_to_rgb(scale * accum) (src/main.rs:71-75,160-164) into an RGB24 image with row pitch. */
+int pt_read_rgb8(pt_ctx *ctx, uint8_t *rgb, uint64_t pitch_bytes);
+/* device address of the W x H x 3 float accumulator, for collectives that combine ranks. */
+int pt_accum_device_ptr(pt_ctx *ctx, void **ptr, uint64_t *n_floats);
+/* add `spp` to the sample count after an external reduce put other ranks' sums in accum. */
+int pt_add_external_samples(pt_ctx *ctx, float spp);
+
+/* BVH::intersect_closest / intersect_any (src/bvh.rs:180-271) over a batch of rays. */
+int pt_trace(pt_ctx *ctx, const pt_ray *rays, uint64_t n, int any_hit, pt_hit *hits);
+/* Scene::sample_skybox (src/scene.rs:162-169) for n directions (n x 3 floats) -> n x 3 floats. */
+int pt_sample_skybox(pt_ctx *ctx, const float *dirs, uint64_t n, float *rgb);
+
+int pt_get_counters(pt_ctx *ctx, pt_counters *out);
+int pt_reset_counters(pt_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTCORE_H */

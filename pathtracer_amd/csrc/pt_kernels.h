@@ -1,0 +1,90 @@
+// pt_kernels.h — device data layout and the host-callable launchers of the gfx950 kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ptcore.h"
+
+namespace pt {
+
+enum { PRIM_TRIANGLE = 0, PRIM_SPHERE = 1 };
+
+// Read-only scene data resident in HBM (replicated per GPU).  See DESIGN.md "Data layout".
+struct DevScene {
+    const float4* pairs;       // 4 x float4 (64 B) per internal node: {Lmin,Lref}{Lmax,0}{Rmin,Rref}{Rmax,0}
+    const float4* prim;        // triangles: 3 x float4 per slot {p0.xyz,e1.x}{e1.yz,e2.xy}{e2.z,id,mat,0}
+                               // spheres:   1 x float4 per slot {c.xyz, r}
+    const uint32_t* prim_meta; // spheres: 2 x u32 per slot {object id, material}
+    const float* nrm;          // triangles: 9 floats per slot (normal0..2), leaf order
+    const uint32_t* big_leaf;  // (first, count) of leaves with > 31 primitives
+    const pt_material* mats;
+    const float* sky;          // 2500 x 1250 x 3 floats + zero padding up to kSkyMaxIndex
+    const uint32_t* lights;    // slots of emissive primitives
+    uint32_t n_lights;
+    uint32_t n_prims;
+    uint32_t root_ref;
+    uint32_t stack_cap;        // most entries a traversal can postpone (= tree levels - 1)
+    float root_min[3], root_max[3];
+};
+
+// Camera after update() (src/camera.rs:271-292), in device memory.
+struct DevCamera {
+    float origin[3], p1[3], p2[3], p3[3], right[3], up[3], direction[3], target[3];
+    float focal_distance, lens_size;
+    uint32_t width, height;
+};
+
+// slot -> pixel mapping of one render call: 8x8 pixel tiles per wave for coherent primary rays,
+// grouped in `tile` x `tile` blocks that are dealt round-robin to ranks.
+struct PixelMap {
+    uint32_t width, height;
+    uint32_t tile;        // edge of a rank tile (multiple of 8)
+    uint32_t tiles_x, tiles_y;
+    uint32_t rank, nranks;
+    uint32_t n_local_tiles;
+    uint32_t npix_pad;    // n_local_tiles * tile * tile
+};
+
+// Per-path state, structure of float4 arrays indexed by slot = s_local * npix_pad + idx.
+struct PathState {
+    float4* ro;   // origin.xyz, ray.distance
+    float4* rd;   // direction.xyz, cos_intersection saved across the look-ahead trace
+    float4* hit;  // bits(slot | inside << 31) or PT_MISS, ray.distance after the trace, u, v
+    float4* tp;   // transport.rgb, bits(iteration | phase << 16 | material << 17)
+    float4* out;  // radiance of the finished path
+    float4* acc;  // accumalated_color while the path is alive (only scenes whose NEE weight is non-zero)
+    uint2* pxs;   // pixel index (y * width + x) and global sample index: the RNG counter words
+};
+
+enum { CNT_PATHS = 0, CNT_RAYS_CLOSEST, CNT_RAYS_ANY, CNT_NODE_TESTS, CNT_PRIM_TESTS, CNT_N };
+
+struct LaunchCfg {
+    uint32_t grid;          // workgroups of the persistent traversal launch
+    unsigned long long* spill;  // overflow of the per-lane LDS stacks: [level][grid * block]
+    uint32_t spill_stride;  // grid * block
+};
+
+constexpr int kTraceBlock = 256;  // threads per traversal workgroup
+constexpr int kLdsStack = 12;     // stack entries per lane kept in LDS
+
+// parity seams
+void launch_trace(int prim, bool any_hit, bool count, const DevScene& S, const pt_ray* rays, uint64_t n, pt_hit* hits,
+                  const LaunchCfg& cfg, unsigned long long* counters, hipStream_t st);
+void launch_generate(const DevCamera* cam, const uint32_t* xy, uint64_t n, uint32_t sample, uint32_t k0, uint32_t k1, pt_ray* rays,
+                     hipStream_t st);
+void launch_sky(const DevScene& S, const float* dirs, uint64_t n, float* rgb, hipStream_t st);
+void launch_focus(int prim, const DevScene& S, DevCamera* cam, const LaunchCfg& cfg, hipStream_t st);
+
+// the wavefront pipeline
+void launch_raygen(const DevCamera* cam, const PixelMap& M, const PathState& P, uint32_t n_samples, uint32_t sample_base, uint32_t k0,
+                   uint32_t k1, bool nee, uint32_t* queue, uint32_t* qn, unsigned long long* counters, hipStream_t st);
+void launch_extend(int prim, bool count, const DevScene& S, const PathState& P, const uint32_t* queue, const uint32_t* qn,
+                   const LaunchCfg& cfg, unsigned long long* counters, hipStream_t st);
+void launch_shade(int prim, bool nee, const DevScene& S, const PathState& P, const PixelMap& M, const uint32_t* q_in, const uint32_t* qn_in,
+                  uint32_t* q_out, uint32_t* qn_out, uint32_t depth, uint32_t sample_base, uint32_t k0, uint32_t k1,
+                  const LaunchCfg& cfg, unsigned long long* counters, hipStream_t st);
+void launch_accumulate(const PixelMap& M, const float4* out, uint32_t n_samples, float* accum, hipStream_t st);
+void launch_resolve(const float* accum, uint32_t width, uint32_t height, float scale, uint8_t* rgb, uint64_t pitch, hipStream_t st);
+
+}  // namespace pt

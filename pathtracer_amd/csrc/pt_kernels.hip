@@ -1,0 +1,754 @@
+// pt_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the path-tracing hot path.
+//
+//   k_raygen      Camera::generate                      src/camera.rs:426-449
+//   k_extend      BVH::intersect_closest                src/bvh.rs:180-226  (+ triangle.rs:41-79, sphere.rs:34-80)
+//   k_shade       body of the loop in Camera::sample    src/camera.rs:299-421 (+ scene.rs:162-169)
+//                 and wave64 ballot/mbcnt compaction of the surviving paths
+//   k_accumulate  chunk[idx] += sample                  src/main.rs:159
+//   k_resolve     vec_to_rgb(scale * accum)             src/main.rs:71-75,160-164
+//   k_trace / k_generate / k_sky / k_focus              parity seams and Camera::update + focus
+//
+// Traversal keeps the reference's exact visiting order (near child first by `tlmin <= trmin`,
+// last accepted primitive wins, no distance test for triangles), so hit ids are bit-exact.
+// The only restructurings are ones that cannot change a result:
+//   * 1/direction is computed once per ray instead of once per AABB test;
+//   * the reference re-tests a node's AABB when it is popped (bvh.rs:196).  tmin/tmax of that
+//     test do not depend on ray.distance, so the re-test reduces to `!(ray.distance < tmin)`
+//     with the tmin computed when the node was pushed; tmin is kept on the stack instead of
+//     re-fetching the node.  The near child is visited directly (its re-test happens with an
+//     unchanged ray.distance and always passes);
+//   * normal / area of a hit are computed once for the winning primitive, in the shade kernel.
+// Built with -ffp-contract=off: every float op is a single IEEE-754 operation.
+#include "pt_kernels.h"
+
+#include "pt_bvh.h"
+#include "pt_device.h"
+
+#pragma clang fp contract(off)
+
+namespace pt {
+
+__device__ __forceinline__ V3 xyz(float4 v) { return V3{v.x, v.y, v.z}; }
+__device__ __forceinline__ V3 ld3(const float* p) { return V3{p[0], p[1], p[2]}; }
+
+// ------------------------------------------------------------------------------------------------
+// Per-lane traversal stack: the first kLdsStack levels live in LDS laid out [level][thread] so that
+// a wave's accesses hit 64 consecutive 8-byte words whatever level each lane is at (no bank
+// conflicts under divergence); deeper levels spill to a global array with the same shape.
+// One entry = (child reference, tmin bits) packed in 64 bits.
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+struct LaneStack {
+    lds_u64* lds;         // &smem[threadIdx.x], kept in the LDS address space so accesses are ds_read/ds_write_b64
+    unsigned long long* spill;  // &spill[global thread id]
+    uint32_t spill_stride;
+    __device__ __forceinline__ void put(uint32_t level, uint32_t ref, float tmin) {
+        const unsigned long long e = (unsigned long long)ref | ((unsigned long long)__float_as_uint(tmin) << 32);
+        if (level < (uint32_t)kLdsStack) lds[level * kTraceBlock] = e;
+        else spill[(size_t)(level - kLdsStack) * spill_stride] = e;
+    }
+    __device__ __forceinline__ void get(uint32_t level, uint32_t* ref, float* tmin) const {
+        unsigned long long e;
+        if (level < (uint32_t)kLdsStack) e = lds[level * kTraceBlock];
+        else e = spill[(size_t)(level - kLdsStack) * spill_stride];
+        *ref = (uint32_t)e;
+        *tmin = __uint_as_float((uint32_t)(e >> 32));
+    }
+};
+
+struct Hit {
+    uint32_t slot;    // leaf-order primitive slot, PT_MISS if none
+    float u, v;       // barycentrics of the winning triangle
+    uint32_t inside;  // Intersection::inside
+};
+
+// BVH::intersect_closest (ANY = false) / intersect_any (ANY = true).  `dist` is ray.distance
+// (in/out).  COUNT adds the algorithmic work counters used for the roofline.
+template <int PRIM, bool ANY, bool COUNT>
+__device__ __forceinline__ void traverse(const DevScene& S, V3 o, V3 d, float& dist, Hit& hit, LaneStack stk,
+                                         uint32_t& n_node_tests, uint32_t& n_prim_tests) {
+    hit.slot = PT_MISS;
+    hit.u = hit.v = 0.0f;
+    hit.inside = 0;
+    const V3 rcp = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+    float tmin;
+    if (COUNT) n_node_tests += 1;
+    if (!slab(S.root_min[0], S.root_min[1], S.root_min[2], S.root_max[0], S.root_max[1], S.root_max[2], o, rcp, dist, &tmin)) return;
+    uint32_t cur = S.root_ref;
+    uint32_t sp = 0;
+    while (true) {
+        bool need_pop;
+        if (!(cur & kLeafBit)) {
+            const float4* rec = S.pairs + (size_t)cur * 4;
+            const float4 a = rec[0], b = rec[1], c = rec[2], e = rec[3];
+            float tl, tr;
+            const bool hl = slab(a.x, a.y, a.z, b.x, b.y, b.z, o, rcp, dist, &tl);
+            const bool hr = slab(c.x, c.y, c.z, e.x, e.y, e.z, o, rcp, dist, &tr);
+            if (COUNT) n_node_tests += 2;
+            const uint32_t lref = __float_as_uint(a.w), rref = __float_as_uint(c.w);
+            if (hl && hr) {
+                const bool left_first = tl <= tr;  // bvh.rs:211
+                stk.put(sp, left_first ? rref : lref, left_first ? tr : tl);
+                sp += 1;
+                cur = left_first ? lref : rref;
+                need_pop = false;
+            } else if (hl) {
+                cur = lref;
+                need_pop = false;
+            } else if (hr) {
+                cur = rref;
+                need_pop = false;
+            } else {
+                need_pop = true;
+            }
+        } else {
+            uint32_t first = cur & kLeafFirstMask;
+            uint32_t count = (cur >> kLeafCountShift) & 31u;
+            if (count == 0) {
+                count = S.big_leaf[2 * first + 1];
+                first = S.big_leaf[2 * first];
+            }
+            if (COUNT) n_prim_tests += count;
+            for (uint32_t k = 0; k < count; ++k) {
+                const uint32_t slot = first + k;
+                if (PRIM == PRIM_TRIANGLE) {
+                    const float4* tp = S.prim + (size_t)slot * 3;
+                    const float4 a = tp[0], b = tp[1], c = tp[2];
+                    float t, u, v, det;
+                    if (tri_hit(V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, V3{b.z, b.w, c.x}, o, d, &t, &u, &v, &det)) {
+                        dist = t;  // unconditionally, triangle.rs:72
+                        hit.slot = slot;
+                        hit.u = u;
+                        hit.v = v;
+                        hit.inside = det < 0.0f ? 1u : 0u;
+                        if (ANY) return;
+                    }
+                } else {
+                    const float4 s = S.prim[slot];
+                    float t;
+                    bool inside;
+                    if (sphere_hit(V3{s.x, s.y, s.z}, s.w, o, d, dist, &t, &inside)) {
+                        dist = t;
+                        hit.slot = slot;
+                        hit.inside = inside ? 1u : 0u;
+                        if (ANY) return;
+                    }
+                }
+            }
+            need_pop = true;
+        }
+        if (need_pop) {
+            // bvh.rs:194-196: pop, re-test against the current ray.distance
+            while (true) {
+                if (sp == 0) return;
+                sp -= 1;
+                uint32_t ref;
+                float tpush;
+                stk.get(sp, &ref, &tpush);
+                if (!(dist < tpush)) {
+                    cur = ref;
+                    break;
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ LaneStack make_stack(unsigned long long* smem, const LaunchCfg& cfg) {
+    LaneStack s;
+    s.lds = (lds_u64*)smem + threadIdx.x;
+    s.spill = cfg.spill + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    s.spill_stride = cfg.spill_stride;
+    return s;
+}
+
+// wave-level sum -> one atomic per wave
+__device__ __forceinline__ void wave_add(unsigned long long* dst, uint32_t v) {
+    unsigned long long s = v;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(dst, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// parity seam: BVH::intersect_closest / intersect_any over a batch of caller rays
+template <int PRIM, bool ANY, bool COUNT>
+__global__ __launch_bounds__(kTraceBlock) void k_trace(DevScene S, const pt_ray* __restrict__ rays, uint64_t n, pt_hit* __restrict__ hits,
+                                                       LaunchCfg cfg, unsigned long long* counters) {
+    __shared__ unsigned long long smem[kLdsStack * kTraceBlock];
+    LaneStack stk = make_stack(smem, cfg);
+    uint32_t nn = 0, np = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * kTraceBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kTraceBlock) {
+        const pt_ray r = rays[i];
+        float dist = r.tmax;
+        Hit h;
+        traverse<PRIM, ANY, COUNT>(S, V3{r.o[0], r.o[1], r.o[2]}, V3{r.d[0], r.d[1], r.d[2]}, dist, h, stk, nn, np);
+        pt_hit out;
+        out.prim = PT_MISS;
+        out.t = dist;
+        out.inside = 0;
+        if (h.slot != PT_MISS) {
+            out.prim = PRIM == PRIM_TRIANGLE ? __float_as_uint(S.prim[(size_t)h.slot * 3 + 2].y) : S.prim_meta[2 * h.slot];
+            out.inside = h.inside;
+        }
+        hits[i] = out;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(counters + (ANY ? CNT_RAYS_ANY : CNT_RAYS_CLOSEST), (unsigned long long)n);
+    if (COUNT) {
+        wave_add(counters + CNT_NODE_TESTS, nn);
+        wave_add(counters + CNT_PRIM_TESTS, np);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// material / geometry of a hit (winning primitive only)
+struct Surface {
+    V3 normal;
+    float area;
+    uint32_t mat;
+};
+template <int PRIM>
+__device__ __forceinline__ Surface surface_at(const DevScene& S, uint32_t slot, float u, float v, V3 o, V3 d, float t, bool want_area) {
+    Surface s;
+    if (PRIM == PRIM_TRIANGLE) {
+        const float4* tp = S.prim + (size_t)slot * 3;
+        const float4 a = tp[0], b = tp[1], c = tp[2];
+        const float* n = S.nrm + (size_t)slot * 9;
+        s.normal = tri_normal(ld3(n), ld3(n + 3), ld3(n + 6), u, v);
+        s.mat = __float_as_uint(c.z);
+        s.area = want_area ? tri_area(V3{a.w, b.x, b.y}, V3{b.z, b.w, c.x}) : 0.0f;
+    } else {
+        const float4 sp = S.prim[slot];
+        s.normal = sphere_normal(V3{sp.x, sp.y, sp.z}, o, d, t);
+        s.mat = S.prim_meta[2 * slot + 1];
+        s.area = want_area ? sphere_area(sp.w) : 0.0f;
+    }
+    return s;
+}
+
+__device__ __forceinline__ V3 sky_lookup(const DevScene& S, V3 d) {
+    uint32_t idx = sky_index(d);
+    if (idx > kSkyMaxIndex) return V3{0.f, 0.f, 0.f};
+    const float* p = S.sky + (size_t)idx * 3;
+    return V3{p[0], p[1], p[2]};
+}
+
+// slot index inside one sample -> pixel
+__device__ __forceinline__ bool map_pixel(const PixelMap& M, uint32_t idx, uint32_t* x_out, uint32_t* y_out) {
+    const uint32_t per_tile = M.tile * M.tile;
+    const uint32_t local_tile = idx / per_tile, within = idx % per_tile;
+    const uint32_t T = local_tile * M.nranks + M.rank;
+    const uint32_t tx = T % M.tiles_x, ty = T / M.tiles_x;
+    const uint32_t sub = within >> 6, lane = within & 63u;
+    const uint32_t subs = M.tile >> 3;
+    const uint32_t x = tx * M.tile + (sub % subs) * 8 + (lane & 7u);
+    const uint32_t y = ty * M.tile + (sub / subs) * 8 + (lane >> 3);
+    *x_out = x;
+    *y_out = y;
+    return x < M.width && y < M.height;
+}
+
+
+// Camera::generate, src/camera.rs:426-449
+__device__ __forceinline__ void generate_ray(const DevCamera& cam, uint32_t x, uint32_t y, uint32_t sample, uint32_t k0, uint32_t k1,
+                                             V3* o_out, V3* d_out) {
+    const U4 r = philox4x32_10(k0, k1, y * cam.width + x, sample, 0u, 0u);
+    const float r0 = closed01(r.v[0]);
+    const float r1 = closed01(r.v[1]);
+    const float r2 = closed01(r.v[2]) - 0.5f;
+    const float r3 = closed01(r.v[3]) - 0.5f;
+    const float u = ((float)x + r0) / (float)cam.width;
+    const float v = ((float)y + r1) / (float)cam.height;
+    const V3 p1 = ld3(cam.p1), p2 = ld3(cam.p2), p3 = ld3(cam.p3);
+    const V3 target = (p1 + u * (p2 - p1)) + v * (p3 - p1);
+    const V3 origin = ld3(cam.origin) + cam.lens_size * (r2 * ld3(cam.right) + r3 * ld3(cam.up));
+    *o_out = origin;
+    *d_out = normalize(target - origin);
+}
+
+__global__ void k_generate(const DevCamera* __restrict__ camp, const uint32_t* __restrict__ xy, uint64_t n, uint32_t sample, uint32_t k0,
+                           uint32_t k1, pt_ray* __restrict__ rays) {
+    const DevCamera cam = *camp;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        V3 o, d;
+        generate_ray(cam, xy[2 * i], xy[2 * i + 1], sample, k0, k1, &o, &d);
+        pt_ray r;
+        r.o[0] = o.x; r.o[1] = o.y; r.o[2] = o.z;
+        r.d[0] = d.x; r.d[1] = d.y; r.d[2] = d.z;
+        r.tmax = kInf;
+        rays[i] = r;
+    }
+}
+
+__global__ void k_sky(DevScene S, const float* __restrict__ dirs, uint64_t n, float* __restrict__ rgb) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const V3 c = sky_lookup(S, ld3(dirs + 3 * i));
+        rgb[3 * i] = c.x;
+        rgb[3 * i + 1] = c.y;
+        rgb[3 * i + 2] = c.z;
+    }
+}
+
+// Camera::update + Camera::focus, src/camera.rs:214-292.  One lane walks the (at most five)
+// deterministic autofocus segments with the same traversal the renderer uses.
+template <int PRIM>
+__global__ __launch_bounds__(kTraceBlock) void k_focus(DevScene S, DevCamera* camp, LaunchCfg cfg) {
+    __shared__ unsigned long long smem[kLdsStack * kTraceBlock];
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    LaneStack stk = make_stack(smem, cfg);
+    DevCamera cam = *camp;
+    const V3 origin = ld3(cam.origin), target = ld3(cam.target);
+    const V3 direction = normalize(target - origin);
+    const V3 right = cross(V3{0.f, 1.f, 0.f}, direction);
+    const V3 up = cross(direction, right);
+    const float aspect = (float)cam.width / (float)cam.height;
+
+    V3 o = origin, d = direction;
+    float distance = 0.0f;
+    int depth = 5;
+    float focus;
+    uint32_t nn = 0, np = 0;
+    while (true) {
+        if (depth == 0) { focus = distance; break; }
+        float dist = kInf;
+        Hit h;
+        traverse<PRIM, false, false>(S, o, d, dist, h, stk, nn, np);
+        if (h.slot == PT_MISS) { focus = distance == 0.0f ? kInf : distance; break; }
+        distance = distance + dist;
+        const Surface sf = surface_at<PRIM>(S, h.slot, h.u, h.v, o, d, dist, false);
+        const pt_material m = S.mats[sf.mat];
+        const V3 P = o + dist * d;
+        V3 nd;
+        if (m.kind == PT_MAT_DIFFUSE && m.a > 0.5f) {
+            nd = reflect(d, sf.normal);
+        } else if (m.kind == PT_MAT_DIELECTRIC) {
+            const bool inside = h.inside != 0;
+            const V3 nf = inside ? -sf.normal : sf.normal;
+            const float na = inside ? m.b : m.a, nb = inside ? m.a : m.b;
+            V3 refr;
+            if (refract(d, nf, na, nb, &refr)) nd = 0.5f < schlick(d, nf, na, nb) ? reflect(d, nf) : refr;
+            else nd = reflect(d, nf);
+        } else {
+            focus = distance == 0.0f ? kInf : distance;
+            break;
+        }
+        o = advance(P, nd);
+        d = nd;
+        depth -= 1;
+    }
+    const float fd = fmin_(20.0f, focus);
+    const V3 c = origin + fd * direction;
+    const V3 p1 = (c + (-0.5f * fd * aspect) * right) + (0.5f * fd) * up;
+    const V3 p2 = (c + (0.5f * fd * aspect) * right) + (0.5f * fd) * up;
+    const V3 p3 = (c + (-0.5f * fd * aspect) * right) + (-0.5f * fd) * up;
+    cam.focal_distance = fd;
+    cam.direction[0] = direction.x; cam.direction[1] = direction.y; cam.direction[2] = direction.z;
+    cam.right[0] = right.x; cam.right[1] = right.y; cam.right[2] = right.z;
+    cam.up[0] = up.x; cam.up[1] = up.y; cam.up[2] = up.z;
+    cam.p1[0] = p1.x; cam.p1[1] = p1.y; cam.p1[2] = p1.z;
+    cam.p2[0] = p2.x; cam.p2[1] = p2.y; cam.p2[2] = p2.z;
+    cam.p3[0] = p3.x; cam.p3[1] = p3.y; cam.p3[2] = p3.z;
+    *camp = cam;
+}
+
+// ------------------------------------------------------------------------------------------------
+// wave64 stream compaction: every lane of the wave must call this (uniform control flow).
+// One atomic per wave; lanes get consecutive places in `q` in lane order.
+__device__ __forceinline__ void wave_enqueue(bool keep, uint32_t value, uint32_t* __restrict__ q, uint32_t* __restrict__ qn) {
+    const unsigned long long m = __ballot(keep);
+    if (m == 0) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(qn, (uint32_t)__popcll(m));
+    base = __shfl(base, 0, 64);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if (keep) q[base + rank] = value;
+}
+
+constexpr uint32_t kPhaseBit = 1u << 16;
+constexpr uint32_t kMatShift = 17;
+
+__global__ __launch_bounds__(256) void k_raygen(const DevCamera* __restrict__ camp, PixelMap M, PathState P, uint32_t n_samples,
+                                                uint32_t sample_base, uint32_t k0, uint32_t k1, int nee, uint32_t* __restrict__ queue,
+                                                uint32_t* __restrict__ qn, unsigned long long* counters) {
+    const DevCamera cam = *camp;
+    const uint32_t total = n_samples * M.npix_pad;
+    uint32_t made = 0;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < total; base += gridDim.x * blockDim.x) {
+        const uint32_t slot = base + threadIdx.x;
+        bool valid = false;
+        if (slot < total) {
+            const uint32_t s_local = slot / M.npix_pad, idx = slot - s_local * M.npix_pad;
+            uint32_t x, y;
+            valid = map_pixel(M, idx, &x, &y);
+            if (valid) {
+                V3 o, d;
+                const uint32_t sample = sample_base + s_local;
+                generate_ray(cam, x, y, sample, k0, k1, &o, &d);
+                P.ro[slot] = make_float4(o.x, o.y, o.z, kInf);
+                P.rd[slot] = make_float4(d.x, d.y, d.z, 0.0f);
+                P.tp[slot] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(0u));
+                P.pxs[slot] = make_uint2(y * M.width + x, sample);
+                if (nee) P.acc[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+                made += 1;
+            }
+        }
+        wave_enqueue(valid, slot, queue, qn);
+    }
+    wave_add(counters + CNT_PATHS, made);
+}
+
+// BVH::intersect_closest for every queued path
+template <int PRIM, bool COUNT>
+__global__ __launch_bounds__(kTraceBlock) void k_extend(DevScene S, PathState P, const uint32_t* __restrict__ queue,
+                                                        const uint32_t* __restrict__ qn, LaunchCfg cfg, unsigned long long* counters) {
+    __shared__ unsigned long long smem[kLdsStack * kTraceBlock];
+    LaneStack stk = make_stack(smem, cfg);
+    const uint32_t n = *qn;
+    uint32_t nn = 0, np = 0;
+    for (uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x; i < n; i += gridDim.x * kTraceBlock) {
+        const uint32_t slot = queue[i];
+        const float4 ro = P.ro[slot], rd = P.rd[slot];
+        float dist = ro.w;
+        Hit h;
+        traverse<PRIM, false, COUNT>(S, xyz(ro), xyz(rd), dist, h, stk, nn, np);
+        const uint32_t bits = h.slot == PT_MISS ? PT_MISS : (h.slot | (h.inside << 31));
+        P.hit[slot] = make_float4(__uint_as_float(bits), dist, h.u, h.v);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(counters + CNT_RAYS_CLOSEST, (unsigned long long)n);
+    if (COUNT) {
+        wave_add(counters + CNT_NODE_TESTS, nn);
+        wave_add(counters + CNT_PRIM_TESTS, np);
+    }
+}
+
+template <int PRIM>
+__device__ __forceinline__ uint32_t prim_material(const DevScene& S, uint32_t slot) {
+    return PRIM == PRIM_TRIANGLE ? __float_as_uint(S.prim[(size_t)slot * 3 + 2].z) : S.prim_meta[2 * slot + 1];
+}
+
+__device__ __forceinline__ void finish(const PathState& P, uint32_t slot, V3 radiance) {
+    P.out[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+}
+
+// One step of the loop body of Camera::sample (src/camera.rs:299-421) for one path.
+// Returns true when the path stays alive (its next ray is in P.ro / P.rd).
+template <int PRIM, bool NEE>
+__device__ __forceinline__ bool shade_one(const DevScene& S, const PathState& P, uint32_t slot, uint32_t depth, uint32_t k0, uint32_t k1,
+                                          LaneStack stk, unsigned long long* counters) {
+    const float4 h = P.hit[slot], ro = P.ro[slot], rd = P.rd[slot], tp = P.tp[slot];
+    const V3 o = xyz(ro), d = xyz(rd);
+    V3 transport = xyz(tp);
+    const uint32_t flags = __float_as_uint(tp.w);
+    uint32_t it = flags & 0xffffu;
+    const uint32_t hbits = __float_as_uint(h.x);
+    const bool is_hit = hbits != PT_MISS;
+    const uint32_t hslot = hbits & 0x7fffffffu;
+    const bool inside = (hbits >> 31) != 0;
+    const float t = h.y;  // ray.distance after the trace
+    V3 acc = V3{0.f, 0.f, 0.f};
+    if (NEE) acc = xyz(P.acc[slot]);
+
+    if (flags & kPhaseBit) {
+        // second half of the diffuse branch, camera.rs:361-372: the look-ahead trace has returned
+        const float cos_i = rd.w;
+        float light_pdf = 0.0f;
+        if (is_hit) {
+            const uint32_t lm = prim_material<PRIM>(S, hslot);
+            if (S.mats[lm].kind == PT_MAT_EMISSIVE) {
+                const Surface sf = surface_at<PRIM>(S, hslot, h.z, h.w, o, d, t, true);
+                const float cos_l = -dot(sf.normal, d);
+                const float solid = (cos_l * sf.area) / (t * t);
+                light_pdf = 1.0f / solid;
+            }
+        }
+        const pt_material m = S.mats[flags >> kMatShift];
+        const V3 brdf = kFrac1Pi * V3{m.rgb[0], m.rgb[1], m.rgb[2]};
+        const float hemi_pdf = kFrac1Pi * cos_i;
+        const float mis = light_pdf + hemi_pdf;
+        transport = mul_ew(transport, (cos_i / mis) * brdf);
+        it += 1;
+        if (it >= depth) { finish(P, slot, acc); return false; }
+        // the next iteration re-traces this ray with the shortened ray.distance (quirk Q3)
+        P.ro[slot] = make_float4(o.x, o.y, o.z, t);
+        P.tp[slot] = make_float4(transport.x, transport.y, transport.z, __uint_as_float(it));
+        return true;
+    }
+
+    if (!is_hit) {  // camera.rs:301-304
+        finish(P, slot, acc + mul_ew(transport, 0.1f * sky_lookup(S, d)));
+        return false;
+    }
+    const V3 Pt = o + t * d;  // ray.intersection(), ray.rs:33-35
+    const Surface sf = surface_at<PRIM>(S, hslot, h.z, h.w, o, d, t, false);
+    const V3 normal = sf.normal;
+    const pt_material m = S.mats[sf.mat];
+    const V3 color = V3{m.rgb[0], m.rgb[1], m.rgb[2]};
+    V3 nd;
+
+    if (m.kind == PT_MAT_EMISSIVE) {  // camera.rs:308-311
+        finish(P, slot, acc + mul_ew(transport, color));
+        return false;
+    } else if (m.kind == PT_MAT_DIFFUSE) {  // camera.rs:312-374
+        const float speculaty = m.a;
+        if (inside) { finish(P, slot, acc); return false; }
+        const uint2 px = P.pxs[slot];
+        if (NEE) {
+            // camera.rs:314-338.  Its weight min(1 - speculaty, 0) is exactly 0 unless speculaty > 1,
+            // and then the block adds nothing, so it only runs when the weight is non-zero.
+            const float nee_w = fmin_(1.0f - speculaty, 0.0f);
+            if (S.n_lights != 0 && nee_w != 0.0f) {
+                const U4 rn = philox4x32_10(k0, k1, px.x, px.y, 1u + it, 1u);
+                const uint32_t lslot = S.lights[rn.v[0] % S.n_lights];
+                V3 Q, ln;
+                float larea, gdist = kInf;
+                bool lhit;
+                if (PRIM == PRIM_TRIANGLE) {
+                    const float4* tpp = S.prim + (size_t)lslot * 3;
+                    const float4 a = tpp[0], b = tpp[1], c = tpp[2];
+                    const V3 p0 = V3{a.x, a.y, a.z}, e1 = V3{a.w, b.x, b.y}, e2 = V3{b.z, b.w, c.x};
+                    const float u = open01(rn.v[1]);
+                    float v = open01(rn.v[2]);
+                    v = (1.0f - u) * v;
+                    Q = (p0 + u * e1) + v * e2;  // triangle.rs:97-104
+                    const V3 ldir = normalize(Q - Pt);
+                    const V3 go = Pt + (20.0f * kEps) * ldir;
+                    float tt, uu, vv, det;
+                    lhit = tri_hit(p0, e1, e2, go, ldir, &tt, &uu, &vv, &det);
+                    if (lhit) {
+                        gdist = tt;
+                        const float* n = S.nrm + (size_t)lslot * 9;
+                        ln = tri_normal(ld3(n), ld3(n + 3), ld3(n + 6), uu, vv);
+                        larea = tri_area(e1, e2);
+                    }
+                } else {
+                    // sphere.rs:98-118 (volume sample, x and y both use cos(phi)); cbrt comes from the
+                    // device math library: this sub-case (sphere light seen from speculaty > 1) is
+                    // not covered by the bit-exact guarantee
+                    const float4 sp = S.prim[lslot];
+                    const float phi = 0.0f + (2.0f * kPi - 0.0f) * half_open01(rn.v[1]);
+                    const float cos_theta = -1.0f + (1.0f - -1.0f) * half_open01(rn.v[2]);
+                    const float uu = 0.0f + (1.0f - 0.0f) * half_open01(rn.v[3]);
+                    const float theta = pt_acosf(cos_theta);
+                    const float rr = sp.w * cbrtf(uu);
+                    float st, ct, sph, cph;
+                    pt_sincosf(theta, &st, &ct);
+                    pt_sincosf(phi, &sph, &cph);
+                    Q = V3{rr * st * cph + sp.x, rr * st * cph + sp.y, rr * ct + sp.z};
+                    const V3 ldir = normalize(Q - Pt);
+                    const V3 go = Pt + (20.0f * kEps) * ldir;
+                    float tt;
+                    bool lin;
+                    lhit = sphere_hit(V3{sp.x, sp.y, sp.z}, sp.w, go, ldir, gdist, &tt, &lin);
+                    if (lhit) {
+                        gdist = tt;
+                        ln = sphere_normal(V3{sp.x, sp.y, sp.z}, go, ldir, tt);
+                        larea = sphere_area(sp.w);
+                    }
+                }
+                if (lhit) {
+                    const V3 ldir = normalize(Q - Pt);
+                    const V3 go = Pt + (20.0f * kEps) * ldir;
+                    const float cos_i = dot(normal, ldir);
+                    const float cos_l = -dot(ln, ldir);
+                    if (cos_i > 0.0f && cos_l > 0.0f) {
+                        gdist -= kEps;
+                        const float gd = gdist;
+                        Hit sh;
+                        uint32_t nn = 0, np = 0;
+                        float dist2 = gdist;
+                        traverse<PRIM, true, false>(S, go, ldir, dist2, sh, stk, nn, np);
+                        atomicAdd(counters + CNT_RAYS_ANY, 1ull);
+                        if (sh.slot == PT_MISS) {
+                            const V3 brdf = kFrac1Pi * color;
+                            const pt_material lmat = S.mats[prim_material<PRIM>(S, lslot)];
+                            const V3 lc = V3{lmat.rgb[0], lmat.rgb[1], lmat.rgb[2]};
+                            const float solid = (cos_l * larea) / (gd * gd);
+                            const float light_pdf = 1.0f / solid;
+                            const float hemi_pdf = kFrac1Pi * cos_i;
+                            const float mis = light_pdf + hemi_pdf;
+                            const V3 nee = (nee_w * (float)S.n_lights) * mul_ew(transport, (cos_i / mis) * mul_ew(lc, brdf));
+                            acc = acc + nee;
+                        }
+                    }
+                }
+            }
+        }
+        const U4 r = philox4x32_10(k0, k1, px.x, px.y, 1u + it, 0u);
+        if (closed01(r.v[0]) < speculaty) {  // camera.rs:341-345
+            nd = reflect(d, normal);
+            transport = mul_ew(transport, color);
+        } else {  // camera.rs:346-373 up to the look-ahead trace
+            const float rr = closed01(r.v[1]);
+            float tm = transport.x > transport.y ? transport.x : transport.y;
+            tm = tm > transport.z ? tm : transport.z;
+            const float survival = fmax_(tm, 0.1f);
+            if (rr < survival) transport = transport / survival;
+            else { finish(P, slot, acc); return false; }
+            nd = cosine_weighted_diffuse(normal, closed01(r.v[2]), closed01(r.v[3]));
+            const V3 no = advance(Pt, nd);
+            const float cos_i = dot(nd, normal);
+            P.ro[slot] = make_float4(no.x, no.y, no.z, kInf);
+            P.rd[slot] = make_float4(nd.x, nd.y, nd.z, cos_i);
+            P.tp[slot] = make_float4(transport.x, transport.y, transport.z, __uint_as_float(it | kPhaseBit | (sf.mat << kMatShift)));
+            if (NEE) P.acc[slot] = make_float4(acc.x, acc.y, acc.z, 0.f);
+            return true;
+        }
+    } else {  // Dielectric, camera.rs:375-417
+        const float n1 = m.a, n2 = m.b;
+        if (inside) {
+            const V3 ab = (V3{-1.f, -1.f, -1.f} + color) * t;
+            transport = mul_ew(transport, V3{pt_expf(ab.x), pt_expf(ab.y), pt_expf(ab.z)});
+        }
+        const V3 nf = inside ? -normal : normal;
+        const float na = inside ? n2 : n1, nb = inside ? n1 : n2;
+        V3 refr;
+        if (refract(d, nf, na, nb, &refr)) {
+            const float sr = schlick(d, nf, na, nb);
+            const uint2 px = P.pxs[slot];
+            const U4 r = philox4x32_10(k0, k1, px.x, px.y, 1u + it, 0u);
+            if (closed01(r.v[0]) < sr) {
+                if (!inside) transport = mul_ew(transport, color);
+                nd = reflect(d, nf);
+            } else {
+                nd = refr;
+            }
+        } else {
+            nd = reflect(d, nf);
+        }
+    }
+    // ray.reset(P, nd, inf) and on to the next iteration
+    it += 1;
+    if (it >= depth) { finish(P, slot, acc); return false; }
+    const V3 no = advance(Pt, nd);
+    P.ro[slot] = make_float4(no.x, no.y, no.z, kInf);
+    P.rd[slot] = make_float4(nd.x, nd.y, nd.z, 0.0f);
+    P.tp[slot] = make_float4(transport.x, transport.y, transport.z, __uint_as_float(it));
+    if (NEE) P.acc[slot] = make_float4(acc.x, acc.y, acc.z, 0.f);
+    return true;
+}
+
+template <int PRIM, bool NEE>
+__global__ __launch_bounds__(kTraceBlock) void k_shade(DevScene S, PathState P, const uint32_t* __restrict__ q_in,
+                                                       const uint32_t* __restrict__ qn_in, uint32_t* __restrict__ q_out,
+                                                       uint32_t* __restrict__ qn_out, uint32_t depth, uint32_t k0, uint32_t k1,
+                                                       LaunchCfg cfg, unsigned long long* counters) {
+    LaneStack stk;
+    stk.lds = nullptr;
+    stk.spill = nullptr;
+    stk.spill_stride = 0;
+    if constexpr (NEE) {
+        __shared__ unsigned long long smem[kLdsStack * kTraceBlock];
+        stk = make_stack(smem, cfg);
+    }
+    const uint32_t n = *qn_in;
+    for (uint32_t base = blockIdx.x * kTraceBlock; base < n; base += gridDim.x * kTraceBlock) {
+        const uint32_t i = base + threadIdx.x;
+        bool alive = false;
+        uint32_t slot = 0;
+        if (i < n) {
+            slot = q_in[i];
+            alive = shade_one<PRIM, NEE>(S, P, slot, depth, k0, k1, stk, counters);
+        }
+        wave_enqueue(alive, slot, q_out, qn_out);
+    }
+}
+
+// chunk[idx] += sample, src/main.rs:159 — samples of one pixel are added in sample order, so the
+// sum is the one the reference's frame loop builds one frame at a time.
+__global__ __launch_bounds__(256) void k_accumulate(PixelMap M, const float4* __restrict__ out, uint32_t n_samples, float* __restrict__ accum) {
+    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < M.npix_pad; idx += gridDim.x * blockDim.x) {
+        uint32_t x, y;
+        if (!map_pixel(M, idx, &x, &y)) continue;
+        float* a = accum + ((size_t)y * M.width + x) * 3;
+        V3 sum = ld3(a);
+        for (uint32_t s = 0; s < n_samples; ++s) sum = sum + xyz(out[(size_t)s * M.npix_pad + idx]);
+        a[0] = sum.x;
+        a[1] = sum.y;
+        a[2] = sum.z;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_resolve(const float* __restrict__ accum, uint32_t width, uint32_t height, float scale,
+                                                 uint8_t* __restrict__ rgb, uint64_t pitch) {
+    const uint32_t n = width * height;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t x = i % width, y = i / width;
+        const V3 v = scale * ld3(accum + (size_t)i * 3);
+        uint8_t* p = rgb + (size_t)y * pitch + (size_t)x * 3;
+        p[0] = tonemap_channel(v.x);
+        p[1] = tonemap_channel(v.y);
+        p[2] = tonemap_channel(v.z);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+static inline uint32_t blocks_for(uint64_t n, uint32_t block, uint32_t cap) {
+    uint64_t b = (n + block - 1) / block;
+    if (b < 1) b = 1;
+    return (uint32_t)(b < cap ? b : cap);
+}
+
+void launch_trace(int prim, bool any_hit, bool count, const DevScene& S, const pt_ray* rays, uint64_t n, pt_hit* hits,
+                  const LaunchCfg& cfg, unsigned long long* counters, hipStream_t st) {
+    const uint32_t grid = blocks_for(n, kTraceBlock, cfg.grid);
+#define PT_TRACE(P, A, C) hipLaunchKernelGGL((k_trace<P, A, C>), dim3(grid), dim3(kTraceBlock), 0, st, S, rays, n, hits, cfg, counters)
+    if (prim == PRIM_TRIANGLE) {
+        if (any_hit) { if (count) PT_TRACE(PRIM_TRIANGLE, true, true); else PT_TRACE(PRIM_TRIANGLE, true, false); }
+        else { if (count) PT_TRACE(PRIM_TRIANGLE, false, true); else PT_TRACE(PRIM_TRIANGLE, false, false); }
+    } else {
+        if (any_hit) { if (count) PT_TRACE(PRIM_SPHERE, true, true); else PT_TRACE(PRIM_SPHERE, true, false); }
+        else { if (count) PT_TRACE(PRIM_SPHERE, false, true); else PT_TRACE(PRIM_SPHERE, false, false); }
+    }
+#undef PT_TRACE
+}
+
+void launch_generate(const DevCamera* cam, const uint32_t* xy, uint64_t n, uint32_t sample, uint32_t k0, uint32_t k1, pt_ray* rays,
+                     hipStream_t st) {
+    hipLaunchKernelGGL(k_generate, dim3(blocks_for(n, 256, 4096)), dim3(256), 0, st, cam, xy, n, sample, k0, k1, rays);
+}
+
+void launch_sky(const DevScene& S, const float* dirs, uint64_t n, float* rgb, hipStream_t st) {
+    hipLaunchKernelGGL(k_sky, dim3(blocks_for(n, 256, 4096)), dim3(256), 0, st, S, dirs, n, rgb);
+}
+
+void launch_focus(int prim, const DevScene& S, DevCamera* cam, const LaunchCfg& cfg, hipStream_t st) {
+    if (prim == PRIM_TRIANGLE) hipLaunchKernelGGL((k_focus<PRIM_TRIANGLE>), dim3(1), dim3(64), 0, st, S, cam, cfg);
+    else hipLaunchKernelGGL((k_focus<PRIM_SPHERE>), dim3(1), dim3(64), 0, st, S, cam, cfg);
+}
+
+void launch_raygen(const DevCamera* cam, const PixelMap& M, const PathState& P, uint32_t n_samples, uint32_t sample_base, uint32_t k0,
+                   uint32_t k1, bool nee, uint32_t* queue, uint32_t* qn, unsigned long long* counters, hipStream_t st) {
+    const uint64_t total = (uint64_t)n_samples * M.npix_pad;
+    hipLaunchKernelGGL(k_raygen, dim3(blocks_for(total, 256, 8192)), dim3(256), 0, st, cam, M, P, n_samples, sample_base, k0, k1,
+                       nee ? 1 : 0, queue, qn, counters);
+}
+
+void launch_extend(int prim, bool count, const DevScene& S, const PathState& P, const uint32_t* queue, const uint32_t* qn,
+                   const LaunchCfg& cfg, unsigned long long* counters, hipStream_t st) {
+#define PT_EXT(PR, C) hipLaunchKernelGGL((k_extend<PR, C>), dim3(cfg.grid), dim3(kTraceBlock), 0, st, S, P, queue, qn, cfg, counters)
+    if (prim == PRIM_TRIANGLE) { if (count) PT_EXT(PRIM_TRIANGLE, true); else PT_EXT(PRIM_TRIANGLE, false); }
+    else { if (count) PT_EXT(PRIM_SPHERE, true); else PT_EXT(PRIM_SPHERE, false); }
+#undef PT_EXT
+}
+
+void launch_shade(int prim, bool nee, const DevScene& S, const PathState& P, const PixelMap& M, const uint32_t* q_in, const uint32_t* qn_in,
+                  uint32_t* q_out, uint32_t* qn_out, uint32_t depth, uint32_t sample_base, uint32_t k0, uint32_t k1,
+                  const LaunchCfg& cfg, unsigned long long* counters, hipStream_t st) {
+    (void)M;
+    (void)sample_base;
+#define PT_SH(PR, N) hipLaunchKernelGGL((k_shade<PR, N>), dim3(cfg.grid), dim3(kTraceBlock), 0, st, S, P, q_in, qn_in, q_out, qn_out, depth, k0, k1, cfg, counters)
+    if (prim == PRIM_TRIANGLE) { if (nee) PT_SH(PRIM_TRIANGLE, true); else PT_SH(PRIM_TRIANGLE, false); }
+    else { if (nee) PT_SH(PRIM_SPHERE, true); else PT_SH(PRIM_SPHERE, false); }
+#undef PT_SH
+}
+
+void launch_accumulate(const PixelMap& M, const float4* out, uint32_t n_samples, float* accum, hipStream_t st) {
+    hipLaunchKernelGGL(k_accumulate, dim3(blocks_for(M.npix_pad, 256, 8192)), dim3(256), 0, st, M, out, n_samples, accum);
+}
+
+void launch_resolve(const float* accum, uint32_t width, uint32_t height, float scale, uint8_t* rgb, uint64_t pitch, hipStream_t st) {
+    hipLaunchKernelGGL(k_resolve, dim3(blocks_for((uint64_t)width * height, 256, 8192)), dim3(256), 0, st, accum, width, height, scale, rgb, pitch);
+}
+
+}  // namespace pt

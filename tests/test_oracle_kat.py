@@ -1,0 +1,126 @@
+"""Pins the CPU oracle against the only result-pinning artefacts the reference holds for this
+path: the 24 rays of its three inline tests (hit / no-hit as asserted there; t, u, v, inside by
+hand evaluation of the reference formulas)."""
+import numpy as np
+import pytest
+
+INF = np.inf
+
+
+# /root/reference/src/primitive/aabb.rs:96-133 — box = extent((1,1,1)) + extent((-1,-1,3))
+AABB_CASES = [
+    ((0, 0, 0), (0, 0, 1), (1.0, 3.0)),
+    ((0, 0, 0), (0, 0, -1), None),
+    ((0, 0.99, 0), (0, 0, 1), (1.0, 3.0)),
+    ((0, 0, 1.01), (0, 1, 0), (-1.0, 1.0)),
+    ((0, 0, 1), (0, 0, -1), (-2.0, -0.0)),
+    ((0, 0, 2), (0, 0, 1), (-1.0, 1.0)),
+    ((0, 0, 2.5), (0, 0, 1), (-1.5, 0.5)),
+    ((0, 0, 2.5), (0, 0, -1), (-0.5, 1.5)),
+]
+
+
+@pytest.mark.parametrize("o,d,expect", AABB_CASES)
+def test_aabb_kat(orc, o, d, expect):
+    got = orc.aabb_intersect((-1, -1, 1), (1, 1, 3), o, d)
+    if expect is None:
+        assert got is None
+    else:
+        assert got is not None
+        assert got[0] == pytest.approx(expect[0], abs=1e-6) and got[1] == pytest.approx(expect[1], abs=1e-6)
+
+
+def test_aabb_grazing_rays_miss(orc):
+    # the comments at aabb.rs:109 and :114 record that y = 1.0 / z = 1.0 do not work (0 * inf = NaN)
+    assert orc.aabb_intersect((-1, -1, 1), (1, 1, 3), (0, 1.0, 0), (0, 0, 1)) is None
+    assert orc.aabb_intersect((-1, -1, 1), (1, 1, 3), (0, 0, 1.0), (0, 1, 0)) is None
+
+
+# /root/reference/src/primitive/triangle.rs:116-151
+TRI_P = [1, 1, 2, 1, -1, 2, -1, 0, 2]
+TRI_N = [0, 0, -1] * 3
+TRI_CASES = [
+    ((0, 0, 0), (0, 0, 1), dict(t=2.0, u=0.25, v=0.5, inside=False)),
+    ((0, 0, 0), (0, 0, -1), None),
+    ((1, 1, 0), (0, 0, 1), dict(t=2.0, u=0.0, v=0.0, inside=False)),
+    ((0, 0, 2), (0, 1, 0), None),
+    ((0, 0, 2), (0, 0, -1), dict(t=-0.0, inside=True)),
+    ((0, 0, 2), (0, 0, 1), dict(t=0.0, inside=False)),
+    ((0, 0, 2.5), (0, 0, 1), None),
+    ((0, 0, 2.5), (0, 0, -1), dict(t=0.5, inside=True)),
+]
+
+
+@pytest.mark.parametrize("o,d,expect", TRI_CASES)
+def test_triangle_kat(orc, o, d, expect):
+    got = orc.triangle_intersect(TRI_P, TRI_N, o, d)
+    if expect is None:
+        assert got is None
+        return
+    assert got is not None
+    for k, v in expect.items():
+        assert got[k] == v, (k, got[k], v)
+    np.testing.assert_array_equal(got["normal"], np.array([0, 0, -1], np.float32))
+
+
+def test_triangle_ignores_ray_distance(orc):
+    # triangle.rs:68-72 has no `t < ray.distance` test (quirk Q1): a hit beyond tmax is accepted
+    got = orc.triangle_intersect(TRI_P, TRI_N, (0, 0, 0), (0, 0, 1), tmax=0.5)
+    assert got is not None and got["t"] == 2.0
+
+
+def test_triangle_area_formula(orc):
+    # triangle.rs:105-113: 0.5 * (1 - e1^.e2^) * |e1| * |e2|; scene light (right angle, legs 1) -> 0.5
+    got = orc.triangle_intersect([2, 2, 2, 1, 2, 2, 2, 2, 1], [0, -1, 0] * 3, (1.8, 0, 1.8), (0, 1, 0))
+    assert got is not None and got["area"] == 0.5 and got["t"] == 2.0 and got["inside"] is False
+
+
+# /root/reference/src/primitive/sphere.rs:124-160 — Sphere::light((0,0,2), 1)
+SPH_CASES = [
+    ((0, 0, 0), (0, 0, 1), dict(t=1.0, inside=False)),
+    ((0, 0, 0), (0, 0, -1), None),
+    ((0, 1, 0), (0, 0, 1), dict(t=2.0, inside=False)),
+    ((0, 0, 1), (0, 1, 0), dict(t=0.0, inside=False)),
+    ((0, 0, 1), (0, 0, -1), dict(t=0.0, inside=True)),
+    ((0, 0, 2), (0, 0, 1), dict(t=1.0, inside=True)),
+    ((0, 0, 2.5), (0, 0, 1), dict(t=0.5, inside=True)),
+    ((0, 0, 2.5), (0, 0, -1), dict(t=1.5, inside=True)),
+]
+
+
+@pytest.mark.parametrize("o,d,expect", SPH_CASES)
+def test_sphere_kat(orc, o, d, expect):
+    got = orc.sphere_intersect([0, 0, 2, 1], o, d)
+    if expect is None:
+        assert got is None
+        return
+    assert got is not None
+    for k, v in expect.items():
+        assert got[k] == v, (k, got[k], v)
+    assert got["area"] == pytest.approx(np.pi, rel=1e-6)
+
+
+def test_sphere_tests_ray_distance(orc):
+    # sphere.rs:54,66: t >= ray.distance rejects, with equality (quirk Q3)
+    assert orc.sphere_intersect([0, 0, 2, 1], (0, 0, 0), (0, 0, 1), tmax=1.0) is None
+    assert orc.sphere_intersect([0, 0, 2, 1], (0, 0, 0), (0, 0, 1), tmax=1.0001) is not None
+
+
+def test_philox_known_answers(orc):
+    # Random123 kat_vectors for philox4x32-10
+    np.testing.assert_array_equal(orc.philox([0, 0], [0, 0, 0, 0]),
+                                  np.array([0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8], np.uint32))
+    np.testing.assert_array_equal(orc.philox([0xffffffff] * 2, [0xffffffff] * 4),
+                                  np.array([0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd], np.uint32))
+    np.testing.assert_array_equal(orc.philox([0xa4093822, 0x299f31d0], [0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344]),
+                                  np.array([0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1], np.uint32))
+
+
+def test_tonemap(orc):
+    # main.rs:71-75: min(255, 256 * 1.5 * sqrt(c)) as u8
+    assert orc.tonemap(0.0) == 0
+    assert orc.tonemap(1.0) == 255
+    assert orc.tonemap(0.25) == 192
+    assert orc.tonemap(0.01) == 38
+    assert orc.tonemap(float("nan")) == 255
+    assert orc.tonemap(-1.0) == 255  # sqrt(-1) = NaN -> min picks 255
