@@ -98,11 +98,14 @@ typedef struct pt_counters {
     uint64_t paths;          /* generate+sample pairs started */
     uint64_t rays_closest;   /* intersect_closest traversals executed (incl. look-ahead, re-trace) */
     uint64_t rays_any;       /* intersect_any traversals executed */
-    uint64_t node_tests;     /* AABB records tested: 1 (root) + 2 per internal node entered */
-    uint64_t prim_tests;     /* Primitive::intersect calls */
+    uint64_t node_tests;     /* AABB records tested: 1 (root) + 2 per internal node entered (PT_RENDER_COUNT) */
+    uint64_t prim_tests;     /* Primitive::intersect calls (PT_RENDER_COUNT) */
     uint64_t extend_launches;
-    double extend_ms;        /* sum of HIP-event durations of the traversal kernel (timed mode) */
+    double extend_ms;        /* sum of HIP-event durations of the round traversal kernel (PT_RENDER_TIMED) */
     double render_ms;        /* HIP-event duration of all pt_render calls since reset */
+    /* the part of the above done by the fused tail kernel (paths finished outside the rounds) */
+    uint64_t tail_rays, tail_node_tests, tail_prim_tests, tail_launches;
+    double tail_ms;
 } pt_counters;
 
 /* flags for pt_render */
@@ -176,7 +179,21 @@ int pt_trace(pt_ctx *ctx, const pt_ray *rays, uint64_t n, int any_hit, pt_hit *h
 /* Scene::sample_skybox (src/scene.rs:162-169) for n directions (n x 3 floats) -> n x 3 floats. */
 int pt_sample_skybox(pt_ctx *ctx, const float *dirs, uint64_t n, float *rgb);
 
+/* Scheduling knobs of pt_render (no counterpart in the reference; none of them changes a result):
+ *  PT_OPT_BATCH_PATHS     paths kept in flight per batch (default 8 Mi; whole samples per batch)
+ *  PT_OPT_LANES           batches in flight at once, 1..8 (default 8)
+ *  PT_OPT_TAIL_MIN_PATHS  a batch is handed to the fused tail kernel when at most this many paths
+ *  PT_OPT_TAIL_FRACTION   ... or at most batch/fraction paths are still alive (0 = never)
+ *  PT_OPT_TAIL_STREAMS    streams the tail kernels are spread over, 1..4 (default 4)
+ *  PT_OPT_TAIL_PATHS_PER_LANE  paths each tail-kernel lane works through on average (default 2) */
+enum { PT_OPT_BATCH_PATHS = 0, PT_OPT_LANES = 1, PT_OPT_TAIL_MIN_PATHS = 2, PT_OPT_TAIL_FRACTION = 3,
+       PT_OPT_TAIL_STREAMS = 4, PT_OPT_TAIL_PATHS_PER_LANE = 5 };
+int pt_set_option(pt_ctx *ctx, int option, uint64_t value);
 int pt_get_counters(pt_ctx *ctx, pt_counters *out);
+/* Diagnostics of the wavefront loop (no counterpart in the reference): after a pt_render with
+ * PT_RENDER_COUNT, the number of live paths entering each extend round of the last batch, and
+ * the largest node_tests any single traversal needed since the last pt_reset_counters. */
+int pt_get_round_stats(pt_ctx *ctx, uint32_t *queue_sizes, uint32_t cap, uint32_t *n_rounds, uint64_t *max_node_tests);
 int pt_reset_counters(pt_ctx *ctx);
 
 #ifdef __cplusplus

@@ -44,7 +44,9 @@ class CameraState(C.Structure):
 class Counters(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("rays_closest", C.c_uint64), ("rays_any", C.c_uint64),
                 ("node_tests", C.c_uint64), ("prim_tests", C.c_uint64), ("extend_launches", C.c_uint64),
-                ("extend_ms", C.c_double), ("render_ms", C.c_double)]
+                ("extend_ms", C.c_double), ("render_ms", C.c_double), ("tail_rays", C.c_uint64),
+                ("tail_node_tests", C.c_uint64), ("tail_prim_tests", C.c_uint64), ("tail_launches", C.c_uint64),
+                ("tail_ms", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

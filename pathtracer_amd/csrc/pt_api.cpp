@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ptcore.h"
@@ -32,6 +33,24 @@ constexpr uint32_t kMaxMaterials = 1u << 15;   // material id must fit the 15 bi
 constexpr uint32_t kMaxDepth = 0xffffu;        // iteration counter has 16 bits
 constexpr uint64_t kTargetSlots = 8u << 20;    // paths kept in flight per batch (about 8.4 M)
 constexpr uint64_t kMaxSlots = 1ull << 31;
+constexpr uint32_t kMaxLanes = 8;              // batches in flight (one HIP stream + path-state set each)
+constexpr uint64_t kTailMinPaths = 65536;      // hand a batch to the fused tail kernel below this many live paths ...
+constexpr uint64_t kTailFraction = 32;         // ... or below 1/32 of the batch
+
+// One batch in flight.
+struct RenderLane {
+    enum State { IDLE, RUNNING, READY, DRAINING };
+    State state = IDLE;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_check = nullptr, ev_done = nullptr;
+    uint32_t* h_qn = nullptr;  // pinned read-back word
+    DevBuf d_ro, d_rd, d_hit, d_tp, d_out, d_acc, d_pxs, d_q0, d_q1, d_qn, d_spill;
+    PathState ps{};
+    LaunchCfg cfg{};
+    uint64_t cap_slots = 0;
+    uint32_t qn_len = 0;
+    uint32_t batch = 0, ns = 0, sample_base = 0, round = 0, live = 0;
+};
 
 }  // namespace
 
@@ -65,16 +84,19 @@ struct pt_ctx {
     uint32_t samples_done = 0;
 
     // pipeline
-    LaunchCfg cfg{};
-    DevBuf d_spill;
-    PathState ps{};
-    DevBuf d_ro, d_rd, d_hit, d_tp, d_out, d_acc, d_pxs, d_q0, d_q1, d_qn;
-    uint64_t cap_slots = 0;
-    uint32_t qn_len = 0;
+    LaunchCfg cfg{};          // grid geometry; every lane has its own spill area
+    size_t spill_bytes = 16;
+    DevBuf d_spill;           // spill area of the seams (pt_trace, focus)
+    RenderLane lanes[kMaxLanes];
+    hipStream_t tail_stream[4] = {nullptr, nullptr, nullptr, nullptr};  // high priority: the few latency-bound tail waves go first
+    hipEvent_t last_acc_event = nullptr;
+    bool last_acc_valid = false;
+    std::vector<hipEvent_t> ext_events, tail_events;
     DevBuf d_counters;
-    double extend_ms = 0, render_ms = 0;
-    uint64_t extend_launches = 0;
-    uint32_t* h_qn = nullptr;  // pinned read-back word
+    double extend_ms = 0, render_ms = 0, tail_ms = 0;
+    uint64_t extend_launches = 0, tail_launches = 0;
+    uint64_t opt_batch_slots = kTargetSlots, opt_tail_min = kTailMinPaths, opt_tail_fraction = kTailFraction, opt_lanes = kMaxLanes, opt_tail_streams = 4, opt_tail_paths_per_lane = 2;
+    std::vector<uint32_t> round_sizes;  // queue length of every round of the last finished batch
 
     int fail(int code, const std::string& msg) {
         err = msg;
@@ -137,10 +159,14 @@ int pt_create(int device, pt_ctx** out) {
         delete c;
         return PT_ERR_HIP;
     }
-    if (hipHostMalloc((void**)&c->h_qn, 64, hipHostMallocDefault) != hipSuccess) {
-        (void)hipStreamDestroy(c->stream);
-        delete c;
-        return PT_ERR_HIP;
+    {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // numerically lower = higher priority
+        for (int i = 0; i < 4; ++i)
+            if (hipStreamCreateWithPriority(&c->tail_stream[i], hipStreamNonBlocking, i < 2 ? hi : lo) != hipSuccess) {
+                pt_destroy(c);
+                return PT_ERR_HIP;
+            }
     }
     if (dev_alloc(c, c->d_counters, CNT_N * sizeof(unsigned long long)) != PT_OK ||
         hipMemset(c->d_counters.p, 0, CNT_N * sizeof(unsigned long long)) != hipSuccess) {
@@ -162,10 +188,19 @@ void pt_destroy(pt_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->d_pairs, &c->d_prim, &c->d_meta, &c->d_nrm, &c->d_big, &c->d_mats, &c->d_sky, &c->d_lights, &c->d_cam,
-                      &c->d_accum, &c->d_spill, &c->d_ro, &c->d_rd, &c->d_hit, &c->d_tp, &c->d_out, &c->d_acc, &c->d_pxs, &c->d_q0,
-                      &c->d_q1, &c->d_qn, &c->d_counters};
+                      &c->d_accum, &c->d_spill, &c->d_counters};
     for (DevBuf* b : bufs) b->release();
-    if (c->h_qn) (void)hipHostFree(c->h_qn);
+    for (RenderLane& L : c->lanes) {
+        if (L.stream) (void)hipStreamSynchronize(L.stream);
+        DevBuf* lb[] = {&L.d_ro, &L.d_rd, &L.d_hit, &L.d_tp, &L.d_out, &L.d_acc, &L.d_pxs, &L.d_q0, &L.d_q1, &L.d_qn, &L.d_spill};
+        for (DevBuf* b : lb) b->release();
+        if (L.h_qn) (void)hipHostFree(L.h_qn);
+        if (L.ev_check) (void)hipEventDestroy(L.ev_check);
+        if (L.ev_done) (void)hipEventDestroy(L.ev_done);
+        if (L.stream) (void)hipStreamDestroy(L.stream);
+    }
+    for (hipStream_t t : c->tail_stream)
+        if (t) { (void)hipStreamSynchronize(t); (void)hipStreamDestroy(t); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -377,7 +412,8 @@ static int finalize_scene(pt_ctx* c) {
     }
     // overflow area of the LDS stacks: exactly the levels the tree can need beyond kLdsStack
     const uint32_t extra = S.stack_cap > (uint32_t)kLdsStack ? S.stack_cap - kLdsStack : 0;
-    if ((rc = dev_alloc(c, c->d_spill, (size_t)std::max(extra, 1u) * c->cfg.spill_stride * sizeof(unsigned long long)))) return rc;
+    c->spill_bytes = (size_t)std::max(extra, 1u) * c->cfg.spill_stride * sizeof(unsigned long long);
+    if ((rc = dev_alloc(c, c->d_spill, c->spill_bytes))) return rc;
     c->cfg.spill = (unsigned long long*)c->d_spill.p;
     c->built = true;
     c->have_cam = false;
@@ -513,32 +549,134 @@ int pt_sample_skybox(pt_ctx* c, const float* dirs, uint64_t n, float* rgb) {
     return PT_OK;
 }
 
-static int ensure_pipeline(pt_ctx* c, uint64_t slots, uint32_t rounds) {
+// ------------------------------------------------------------------------------------------------
+// The frame loop.  A pt_render call is cut into batches of whole samples (about kTargetSlots
+// paths each).  Up to kMaxLanes batches are in flight at once, each on its own HIP stream with
+// its own path-state buffers, so the latency-bound tail of one batch overlaps the
+// bandwidth-bound first rounds of the next.  Per-pixel sums stay in sample order: the
+// accumulate kernel of batch b waits for the one of batch b-1.
+static int lane_alloc(pt_ctx* c, RenderLane& L, uint64_t slots, uint32_t rounds) {
     int rc;
-    if (slots > c->cap_slots) {
-        if ((rc = dev_alloc(c, c->d_ro, slots * 16))) return rc;
-        if ((rc = dev_alloc(c, c->d_rd, slots * 16))) return rc;
-        if ((rc = dev_alloc(c, c->d_hit, slots * 16))) return rc;
-        if ((rc = dev_alloc(c, c->d_tp, slots * 16))) return rc;
-        if ((rc = dev_alloc(c, c->d_out, slots * 16))) return rc;
-        if ((rc = dev_alloc(c, c->d_pxs, slots * 8))) return rc;
-        if ((rc = dev_alloc(c, c->d_q0, slots * 4))) return rc;
-        if ((rc = dev_alloc(c, c->d_q1, slots * 4))) return rc;
-        c->cap_slots = slots;
+    if (!L.stream) {
+        PT_HIP(c, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        PT_HIP(c, hipEventCreateWithFlags(&L.ev_check, hipEventDisableTiming));
+        PT_HIP(c, hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming));
+        PT_HIP(c, hipHostMalloc((void**)&L.h_qn, 64, hipHostMallocDefault));
     }
-    if (c->nee && c->d_acc.bytes < slots * 16)
-        if ((rc = dev_alloc(c, c->d_acc, slots * 16))) return rc;
-    if (rounds + 2 > c->qn_len) {
-        if ((rc = dev_alloc(c, c->d_qn, (size_t)(rounds + 2) * 4))) return rc;
-        c->qn_len = rounds + 2;
+    if (slots > L.cap_slots) {
+        if ((rc = dev_alloc(c, L.d_ro, slots * 16))) return rc;
+        if ((rc = dev_alloc(c, L.d_rd, slots * 16))) return rc;
+        if ((rc = dev_alloc(c, L.d_hit, slots * 16))) return rc;
+        if ((rc = dev_alloc(c, L.d_tp, slots * 16))) return rc;
+        if ((rc = dev_alloc(c, L.d_out, slots * 16))) return rc;
+        if ((rc = dev_alloc(c, L.d_pxs, slots * 8))) return rc;
+        if ((rc = dev_alloc(c, L.d_q0, slots * 4))) return rc;
+        if ((rc = dev_alloc(c, L.d_q1, slots * 4))) return rc;
+        L.cap_slots = slots;
     }
-    c->ps.ro = (float4*)c->d_ro.p;
-    c->ps.rd = (float4*)c->d_rd.p;
-    c->ps.hit = (float4*)c->d_hit.p;
-    c->ps.tp = (float4*)c->d_tp.p;
-    c->ps.out = (float4*)c->d_out.p;
-    c->ps.acc = (float4*)c->d_acc.p;
-    c->ps.pxs = (uint2*)c->d_pxs.p;
+    if (c->nee && L.d_acc.bytes < slots * 16)
+        if ((rc = dev_alloc(c, L.d_acc, slots * 16))) return rc;
+    if (rounds + 2 > L.qn_len) {
+        if ((rc = dev_alloc(c, L.d_qn, (size_t)(rounds + 2) * 4))) return rc;
+        L.qn_len = rounds + 2;
+    }
+    if (!L.d_spill.p || L.d_spill.bytes < c->spill_bytes)
+        if ((rc = dev_alloc(c, L.d_spill, c->spill_bytes))) return rc;
+    L.ps.ro = (float4*)L.d_ro.p;
+    L.ps.rd = (float4*)L.d_rd.p;
+    L.ps.hit = (float4*)L.d_hit.p;
+    L.ps.tp = (float4*)L.d_tp.p;
+    L.ps.out = (float4*)L.d_out.p;
+    L.ps.acc = (float4*)L.d_acc.p;
+    L.ps.pxs = (uint2*)L.d_pxs.p;
+    L.cfg = c->cfg;
+    L.cfg.spill = (unsigned long long*)L.d_spill.p;
+    return PT_OK;
+}
+
+namespace {
+struct RenderJob {
+    PixelMap M;
+    uint32_t max_depth, rounds, k0, k1;
+    bool timed, count;
+    uint32_t tail_threshold;
+};
+}  // namespace
+
+// enqueue rounds [L.round, upto) of the lane's batch, then an async read-back of the next queue length
+static int lane_issue_rounds(pt_ctx* c, RenderLane& L, const RenderJob& J, uint32_t upto) {
+    uint32_t* q[2] = {(uint32_t*)L.d_q0.p, (uint32_t*)L.d_q1.p};
+    uint32_t* qn = (uint32_t*)L.d_qn.p;
+    unsigned long long* counters = (unsigned long long*)c->d_counters.p;
+    for (uint32_t r = L.round; r < upto; ++r) {
+        if (J.timed) {
+            hipEvent_t a, b;
+            PT_HIP(c, hipEventCreate(&a));
+            PT_HIP(c, hipEventCreate(&b));
+            PT_HIP(c, hipEventRecord(a, L.stream));
+            launch_extend(c->prim_kind, J.count, c->ds, L.ps, q[r & 1], qn + r, L.cfg, counters, L.stream);
+            PT_HIP(c, hipEventRecord(b, L.stream));
+            c->ext_events.push_back(a);
+            c->ext_events.push_back(b);
+        } else {
+            launch_extend(c->prim_kind, J.count, c->ds, L.ps, q[r & 1], qn + r, L.cfg, counters, L.stream);
+        }
+        c->extend_launches += 1;
+        launch_shade(c->prim_kind, c->nee, c->ds, L.ps, J.M, q[r & 1], qn + r, q[(r + 1) & 1], qn + r + 1, J.max_depth, L.sample_base,
+                     J.k0, J.k1, L.cfg, counters, L.stream);
+    }
+    L.round = upto;
+    PT_HIP(c, hipMemcpyAsync(L.h_qn, qn + upto, 4, hipMemcpyDeviceToHost, L.stream));
+    PT_HIP(c, hipEventRecord(L.ev_check, L.stream));
+    PT_HIP(c, hipGetLastError());
+    return PT_OK;
+}
+
+static int lane_start(pt_ctx* c, RenderLane& L, const RenderJob& J, uint32_t batch, uint32_t ns, uint32_t sample_base) {
+    uint32_t* qn = (uint32_t*)L.d_qn.p;
+    L.batch = batch;
+    L.ns = ns;
+    L.sample_base = sample_base;
+    L.round = 0;
+    L.state = RenderLane::RUNNING;
+    PT_HIP(c, hipMemsetAsync(qn, 0, (size_t)(J.rounds + 2) * 4, L.stream));
+    launch_raygen((const DevCamera*)c->d_cam.p, J.M, L.ps, ns, sample_base, J.k0, J.k1, c->nee, (uint32_t*)L.d_q0.p, qn,
+                  (unsigned long long*)c->d_counters.p, L.stream);
+    if (J.max_depth == 0)  // `for _ in 0..0` never runs: every sample is (0,0,0)
+        PT_HIP(c, hipMemsetAsync(L.d_out.p, 0, (size_t)ns * J.M.npix_pad * 16, L.stream));
+    // the first rounds carry almost all rays; look at the queue after three of them
+    return lane_issue_rounds(c, L, J, std::min<uint32_t>(3, J.rounds));
+}
+
+// Hand the batch to its tail stream: (optionally) the fused tail kernel for the paths still alive,
+// then the accumulation of the batch's samples, in batch order.
+static int lane_finish(pt_ctx* c, RenderLane& L, const RenderJob& J, uint32_t live) {
+    hipStream_t ts = c->tail_stream[L.batch % c->opt_tail_streams];
+    PT_HIP(c, hipStreamWaitEvent(ts, L.ev_check, 0));
+    if (live != 0 && L.round < J.rounds) {
+        uint32_t* qn = (uint32_t*)L.d_qn.p;
+        hipEvent_t a = nullptr, b = nullptr;
+        if (J.timed) {
+            PT_HIP(c, hipEventCreate(&a));
+            PT_HIP(c, hipEventCreate(&b));
+            PT_HIP(c, hipEventRecord(a, ts));
+        }
+        launch_tail(c->prim_kind, c->nee, J.count, c->ds, L.ps, (L.round & 1) ? (uint32_t*)L.d_q1.p : (uint32_t*)L.d_q0.p, qn + L.round,
+                    qn + J.rounds + 1, (uint32_t)((live + c->opt_tail_paths_per_lane - 1) / c->opt_tail_paths_per_lane), J.max_depth, J.k0, J.k1, L.cfg, (unsigned long long*)c->d_counters.p, ts);
+        if (J.timed) {
+            PT_HIP(c, hipEventRecord(b, ts));
+            c->tail_events.push_back(a);
+            c->tail_events.push_back(b);
+        }
+        c->tail_launches += 1;
+    }
+    if (c->last_acc_valid) PT_HIP(c, hipStreamWaitEvent(ts, c->last_acc_event, 0));
+    launch_accumulate(J.M, L.ps.out, L.ns, (float*)c->d_accum.p, ts);
+    PT_HIP(c, hipEventRecord(L.ev_done, ts));
+    PT_HIP(c, hipGetLastError());
+    c->last_acc_event = L.ev_done;
+    c->last_acc_valid = true;
+    L.state = RenderLane::DRAINING;
     return PT_OK;
 }
 
@@ -550,7 +688,8 @@ int pt_render(pt_ctx* c, uint32_t spp, uint32_t max_depth, uint64_t seed, const 
     if (spp == 0) return PT_OK;
     PT_HIP(c, hipSetDevice(c->device));
 
-    PixelMap M{};
+    RenderJob J{};
+    PixelMap& M = J.M;
     M.width = c->cam.width;
     M.height = c->cam.height;
     M.tile = 8;
@@ -580,75 +719,103 @@ int pt_render(pt_ctx* c, uint32_t spp, uint32_t max_depth, uint64_t seed, const 
         return PT_OK;
     }
 
-    uint64_t per_batch = std::max<uint64_t>(1, kTargetSlots / M.npix_pad);
+    uint64_t per_batch = std::max<uint64_t>(1, c->opt_batch_slots / M.npix_pad);
     per_batch = std::min<uint64_t>(per_batch, spp);
     if (per_batch * M.npix_pad >= kMaxSlots) return c->fail(PT_ERR_LIMIT, "pt_render: batch too large");
-    const uint32_t rounds = max_depth == 0 ? 0 : 2 * max_depth;  // each iteration traces at most twice
-    int rc = ensure_pipeline(c, per_batch * M.npix_pad, rounds);
-    if (rc) return rc;
-
-    const bool timed = (flags & PT_RENDER_TIMED) != 0;
-    const bool count = (flags & PT_RENDER_COUNT) != 0;
-    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    uint32_t* q[2] = {(uint32_t*)c->d_q0.p, (uint32_t*)c->d_q1.p};
-    uint32_t* qn = (uint32_t*)c->d_qn.p;
-    unsigned long long* counters = (unsigned long long*)c->d_counters.p;
-    float* accum = (float*)c->d_accum.p;
+    const uint64_t batch_slots = per_batch * M.npix_pad;
+    const uint32_t n_batches = (uint32_t)((spp + per_batch - 1) / per_batch);
+    const uint32_t n_lanes = (uint32_t)std::min<uint64_t>(c->opt_lanes, n_batches);
+    J.max_depth = max_depth;
+    J.rounds = max_depth == 0 ? 0 : 2 * max_depth;  // each iteration traces at most twice
+    J.k0 = (uint32_t)seed;
+    J.k1 = (uint32_t)(seed >> 32);
+    J.timed = (flags & PT_RENDER_TIMED) != 0;
+    J.count = (flags & PT_RENDER_COUNT) != 0;
+    J.tail_threshold = c->opt_tail_fraction == 0 ? 0 : (uint32_t)std::max<uint64_t>(c->opt_tail_min, batch_slots / c->opt_tail_fraction);
+    for (uint32_t i = 0; i < n_lanes; ++i) {
+        int rc = lane_alloc(c, c->lanes[i], batch_slots, J.rounds);
+        if (rc) return rc;
+        c->lanes[i].state = RenderLane::IDLE;
+    }
 
     hipEvent_t ev_begin, ev_end;
     PT_HIP(c, hipEventCreate(&ev_begin));
     PT_HIP(c, hipEventCreate(&ev_end));
-    std::vector<hipEvent_t> ext_events;
     PT_HIP(c, hipEventRecord(ev_begin, c->stream));
+    for (uint32_t i = 0; i < n_lanes; ++i) PT_HIP(c, hipStreamWaitEvent(c->lanes[i].stream, ev_begin, 0));
+    for (hipStream_t t : c->tail_stream) PT_HIP(c, hipStreamWaitEvent(t, ev_begin, 0));
+    c->last_acc_valid = false;
+    c->ext_events.clear();
+    c->tail_events.clear();
 
-    uint32_t done = 0;
-    while (done < spp) {
-        const uint32_t ns = (uint32_t)std::min<uint64_t>(per_batch, spp - done);
-        const uint32_t sample_base = sample_begin + done;
-        PT_HIP(c, hipMemsetAsync(qn, 0, (size_t)(rounds + 2) * 4, c->stream));
-        launch_raygen((const DevCamera*)c->d_cam.p, M, c->ps, ns, sample_base, k0, k1, c->nee, q[0], qn, counters, c->stream);
-        if (max_depth == 0) {
-            // `for _ in 0..0` never runs: every sample is (0,0,0)
-            PT_HIP(c, hipMemsetAsync(c->d_out.p, 0, (size_t)ns * M.npix_pad * 16, c->stream));
-        }
-        for (uint32_t r = 0; r < rounds; ++r) {
-            if (timed) {
-                hipEvent_t a, b;
-                PT_HIP(c, hipEventCreate(&a));
-                PT_HIP(c, hipEventCreate(&b));
-                PT_HIP(c, hipEventRecord(a, c->stream));
-                launch_extend(c->prim_kind, count, c->ds, c->ps, q[r & 1], qn + r, c->cfg, counters, c->stream);
-                PT_HIP(c, hipEventRecord(b, c->stream));
-                ext_events.push_back(a);
-                ext_events.push_back(b);
-            } else {
-                launch_extend(c->prim_kind, count, c->ds, c->ps, q[r & 1], qn + r, c->cfg, counters, c->stream);
+    uint32_t next_batch = 0, finished = 0, next_acc = 0;
+    while (finished < n_batches) {
+        bool progressed = false;
+        for (uint32_t i = 0; i < n_lanes; ++i) {
+            RenderLane& L = c->lanes[i];
+            if (L.state == RenderLane::IDLE && next_batch < n_batches) {
+                const uint32_t done = next_batch * (uint32_t)per_batch;
+                const uint32_t ns = (uint32_t)std::min<uint64_t>(per_batch, spp - done);
+                int rc = lane_start(c, L, J, next_batch, ns, sample_begin + done);
+                if (rc) return rc;
+                next_batch += 1;
+                progressed = true;
+            } else if (L.state == RenderLane::RUNNING) {
+                hipError_t q = hipEventQuery(L.ev_check);
+                if (q == hipErrorNotReady) continue;
+                if (q != hipSuccess) return c->fail(PT_ERR_HIP, std::string("pt_render: ") + hipGetErrorString(q));
+                progressed = true;
+                const uint32_t live = *L.h_qn;
+                int rc = PT_OK;
+                if (live == 0 || L.round >= J.rounds || live <= J.tail_threshold) {
+                    L.live = live;
+                    L.state = RenderLane::READY;
+                } else {
+                    rc = lane_issue_rounds(c, L, J, std::min<uint32_t>(L.round + 2, J.rounds));
+                }
+                if (rc) return rc;
             }
-            c->extend_launches += 1;
-            launch_shade(c->prim_kind, c->nee, c->ds, c->ps, M, q[r & 1], qn + r, q[(r + 1) & 1], qn + r + 1, max_depth, sample_base,
-                         k0, k1, c->cfg, counters, c->stream);
-            // stop launching once the queue has drained (checked every other round after the first few)
-            if (r >= 3 && (r & 1) == 1) {
-                PT_HIP(c, hipMemcpyAsync(c->h_qn, qn + r + 1, 4, hipMemcpyDeviceToHost, c->stream));
-                PT_HIP(c, hipStreamSynchronize(c->stream));
-                if (*c->h_qn == 0) break;
+            if (L.state == RenderLane::READY && L.batch == next_acc) {
+                // batches are handed over in order so every pixel's sum is built in sample order
+                int rc = lane_finish(c, L, J, L.live);
+                if (rc) return rc;
+                next_acc += 1;
+                progressed = true;
+            } else if (L.state == RenderLane::DRAINING) {
+                hipError_t q = hipEventQuery(L.ev_done);
+                if (q == hipErrorNotReady) continue;
+                if (q != hipSuccess) return c->fail(PT_ERR_HIP, std::string("pt_render: ") + hipGetErrorString(q));
+                if (J.count) {  // diagnostics: queue length per round of the last finished batch
+                    c->round_sizes.assign(J.rounds + 1, 0);
+                    PT_HIP(c, hipMemcpy(c->round_sizes.data(), L.d_qn.p, (size_t)(J.rounds + 1) * 4, hipMemcpyDeviceToHost));
+                }
+                L.state = RenderLane::IDLE;
+                finished += 1;
+                progressed = true;
             }
         }
-        launch_accumulate(M, c->ps.out, ns, accum, c->stream);
-        PT_HIP(c, hipGetLastError());
-        done += ns;
+        if (!progressed) std::this_thread::yield();  // poll: any lane may be the next one to need the host
     }
+    if (c->last_acc_valid) PT_HIP(c, hipStreamWaitEvent(c->stream, c->last_acc_event, 0));
     PT_HIP(c, hipEventRecord(ev_end, c->stream));
     PT_HIP(c, hipStreamSynchronize(c->stream));
     float ms = 0.f;
     PT_HIP(c, hipEventElapsedTime(&ms, ev_begin, ev_end));
     c->render_ms += ms;
-    for (size_t i = 0; i + 1 < ext_events.size(); i += 2) {
+    for (size_t i = 0; i + 1 < c->ext_events.size(); i += 2) {
         float e = 0.f;
-        PT_HIP(c, hipEventElapsedTime(&e, ext_events[i], ext_events[i + 1]));
+        PT_HIP(c, hipEventElapsedTime(&e, c->ext_events[i], c->ext_events[i + 1]));
         c->extend_ms += e;
     }
-    for (hipEvent_t e : ext_events) (void)hipEventDestroy(e);
+    for (size_t i = 0; i + 1 < c->tail_events.size(); i += 2) {
+        float e = 0.f;
+        PT_HIP(c, hipEventElapsedTime(&e, c->tail_events[i], c->tail_events[i + 1]));
+        c->tail_ms += e;
+    }
+    for (hipEvent_t e : c->ext_events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->tail_events) (void)hipEventDestroy(e);
+    c->ext_events.clear();
+    c->tail_events.clear();
     (void)hipEventDestroy(ev_begin);
     (void)hipEventDestroy(ev_end);
     c->spp += (float)spp;
@@ -706,12 +873,45 @@ int pt_get_counters(pt_ctx* c, pt_counters* out) {
     out->paths = cur[CNT_PATHS];
     out->rays_closest = cur[CNT_RAYS_CLOSEST];
     out->rays_any = cur[CNT_RAYS_ANY];
-    out->node_tests = cur[CNT_NODE_TESTS];
-    out->prim_tests = cur[CNT_PRIM_TESTS];
+    out->node_tests = cur[CNT_NODE_TESTS] + cur[CNT_TAIL_NODE_TESTS];
+    out->prim_tests = cur[CNT_PRIM_TESTS] + cur[CNT_TAIL_PRIM_TESTS];
+    out->tail_rays = cur[CNT_TAIL_RAYS];
+    out->tail_node_tests = cur[CNT_TAIL_NODE_TESTS];
+    out->tail_prim_tests = cur[CNT_TAIL_PRIM_TESTS];
+    out->tail_launches = c->tail_launches;
+    out->tail_ms = c->tail_ms;
     out->extend_launches = c->extend_launches;
     out->extend_ms = c->extend_ms;
     out->render_ms = c->render_ms;
     return PT_OK;
+}
+
+int pt_get_round_stats(pt_ctx* c, uint32_t* queue_sizes, uint32_t cap, uint32_t* n_rounds, uint64_t* max_node_tests) {
+    if (!c) return PT_ERR_INVALID;
+    PT_HIP(c, hipSetDevice(c->device));
+    const uint32_t n = (uint32_t)c->round_sizes.size();
+    if (n_rounds) *n_rounds = n;
+    if (queue_sizes)
+        for (uint32_t i = 0; i < n && i < cap; ++i) queue_sizes[i] = c->round_sizes[i];
+    if (max_node_tests) {
+        unsigned long long cur[CNT_N];
+        PT_HIP(c, hipMemcpy(cur, c->d_counters.p, sizeof(cur), hipMemcpyDeviceToHost));
+        *max_node_tests = cur[CNT_MAX_NODE_TESTS];
+    }
+    return PT_OK;
+}
+
+int pt_set_option(pt_ctx* c, int option, uint64_t value) {
+    if (!c) return PT_ERR_INVALID;
+    switch (option) {
+        case PT_OPT_BATCH_PATHS: c->opt_batch_slots = std::max<uint64_t>(value, 64); return PT_OK;
+        case PT_OPT_LANES: c->opt_lanes = std::min<uint64_t>(std::max<uint64_t>(value, 1), kMaxLanes); return PT_OK;
+        case PT_OPT_TAIL_MIN_PATHS: c->opt_tail_min = value; return PT_OK;
+        case PT_OPT_TAIL_FRACTION: c->opt_tail_fraction = value; return PT_OK;
+        case PT_OPT_TAIL_STREAMS: c->opt_tail_streams = std::min<uint64_t>(std::max<uint64_t>(value, 1), 4); return PT_OK;
+        case PT_OPT_TAIL_PATHS_PER_LANE: c->opt_tail_paths_per_lane = std::max<uint64_t>(value, 1); return PT_OK;
+        default: return c->fail(PT_ERR_INVALID, "pt_set_option: unknown option");
+    }
 }
 
 int pt_reset_counters(pt_ctx* c) {
@@ -719,6 +919,8 @@ int pt_reset_counters(pt_ctx* c) {
     PT_HIP(c, hipSetDevice(c->device));
     PT_HIP(c, hipMemset(c->d_counters.p, 0, CNT_N * sizeof(unsigned long long)));
     c->extend_launches = 0;
+    c->tail_launches = 0;
+    c->tail_ms = 0;
     c->extend_ms = 0;
     c->render_ms = 0;
     return PT_OK;

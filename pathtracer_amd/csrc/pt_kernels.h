@@ -57,7 +57,9 @@ struct PathState {
     uint2* pxs;   // pixel index (y * width + x) and global sample index: the RNG counter words
 };
 
-enum { CNT_PATHS = 0, CNT_RAYS_CLOSEST, CNT_RAYS_ANY, CNT_NODE_TESTS, CNT_PRIM_TESTS, CNT_N };
+// CNT_NODE_TESTS / CNT_PRIM_TESTS are the round kernels' (k_extend, k_trace); the fused tail kernel keeps its own
+enum { CNT_PATHS = 0, CNT_RAYS_CLOSEST, CNT_RAYS_ANY, CNT_NODE_TESTS, CNT_PRIM_TESTS, CNT_MAX_NODE_TESTS, CNT_TAIL_RAYS,
+       CNT_TAIL_NODE_TESTS, CNT_TAIL_PRIM_TESTS, CNT_N };
 
 struct LaunchCfg {
     uint32_t grid;          // workgroups of the persistent traversal launch
@@ -84,6 +86,9 @@ void launch_extend(int prim, bool count, const DevScene& S, const PathState& P, 
 void launch_shade(int prim, bool nee, const DevScene& S, const PathState& P, const PixelMap& M, const uint32_t* q_in, const uint32_t* qn_in,
                   uint32_t* q_out, uint32_t* qn_out, uint32_t depth, uint32_t sample_base, uint32_t k0, uint32_t k1,
                   const LaunchCfg& cfg, unsigned long long* counters, hipStream_t st);
+void launch_tail(int prim, bool nee, bool count, const DevScene& S, const PathState& P, const uint32_t* queue, const uint32_t* qn,
+                 uint32_t* cursor, uint32_t n_hint, uint32_t depth, uint32_t k0, uint32_t k1, const LaunchCfg& cfg, unsigned long long* counters,
+                 hipStream_t st);
 void launch_accumulate(const PixelMap& M, const float4* out, uint32_t n_samples, float* accum, hipStream_t st);
 void launch_resolve(const float* accum, uint32_t width, uint32_t height, float scale, uint8_t* rgb, uint64_t pitch, hipStream_t st);
 

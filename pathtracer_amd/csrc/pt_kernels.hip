@@ -368,11 +368,13 @@ constexpr uint32_t kPhaseBit = 1u << 16;
 constexpr uint32_t kMatShift = 17;
 
 __global__ __launch_bounds__(256) void k_raygen(const DevCamera* __restrict__ camp, PixelMap M, PathState P, uint32_t n_samples,
-                                                uint32_t sample_base, uint32_t k0, uint32_t k1, int nee, uint32_t* __restrict__ queue,
-                                                uint32_t* __restrict__ qn, unsigned long long* counters) {
+                                                uint32_t sample_base, uint32_t k0, uint32_t k1, int nee, int identity,
+                                                uint32_t* __restrict__ queue, uint32_t* __restrict__ qn, unsigned long long* counters) {
     const DevCamera cam = *camp;
     const uint32_t total = n_samples * M.npix_pad;
     uint32_t made = 0;
+    // identity: every slot maps to a pixel (no padding), so queue[slot] = slot needs no compaction
+    if (identity && blockIdx.x == 0 && threadIdx.x == 0) *qn = total;
     for (uint32_t base = blockIdx.x * blockDim.x; base < total; base += gridDim.x * blockDim.x) {
         const uint32_t slot = base + threadIdx.x;
         bool valid = false;
@@ -392,7 +394,11 @@ __global__ __launch_bounds__(256) void k_raygen(const DevCamera* __restrict__ ca
                 made += 1;
             }
         }
-        wave_enqueue(valid, slot, queue, qn);
+        if (identity) {
+            if (valid) queue[slot] = slot;
+        } else {
+            wave_enqueue(valid, slot, queue, qn);
+        }
     }
     wave_add(counters + CNT_PATHS, made);
 }
@@ -404,13 +410,15 @@ __global__ __launch_bounds__(kTraceBlock) void k_extend(DevScene S, PathState P,
     __shared__ unsigned long long smem[kLdsStack * kTraceBlock];
     LaneStack stk = make_stack(smem, cfg);
     const uint32_t n = *qn;
-    uint32_t nn = 0, np = 0;
+    uint32_t nn = 0, np = 0, worst = 0;
     for (uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x; i < n; i += gridDim.x * kTraceBlock) {
         const uint32_t slot = queue[i];
         const float4 ro = P.ro[slot], rd = P.rd[slot];
         float dist = ro.w;
         Hit h;
+        const uint32_t nn0 = nn;
         traverse<PRIM, false, COUNT>(S, xyz(ro), xyz(rd), dist, h, stk, nn, np);
+        if (COUNT) worst = nn - nn0 > worst ? nn - nn0 : worst;
         const uint32_t bits = h.slot == PT_MISS ? PT_MISS : (h.slot | (h.inside << 31));
         P.hit[slot] = make_float4(__uint_as_float(bits), dist, h.u, h.v);
     }
@@ -418,6 +426,12 @@ __global__ __launch_bounds__(kTraceBlock) void k_extend(DevScene S, PathState P,
     if (COUNT) {
         wave_add(counters + CNT_NODE_TESTS, nn);
         wave_add(counters + CNT_PRIM_TESTS, np);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t other = __shfl_down(worst, off, 64);
+            worst = other > worst ? other : worst;
+        }
+        if ((threadIdx.x & 63) == 0 && worst) atomicMax(counters + CNT_MAX_NODE_TESTS, (unsigned long long)worst);
     }
 }
 
@@ -653,6 +667,67 @@ __global__ __launch_bounds__(kTraceBlock) void k_shade(DevScene S, PathState P, 
     }
 }
 
+// The tail of a batch: once few paths are left, per-round launches are bound by the latency of
+// the longest single traversal.  This persistent kernel runs whole remaining paths instead:
+// every lane repeats {trace, shade} on its path and, when the path ends, fetches the next one
+// from the queue (one wave-aggregated atomic per refill), so waves stay full until the queue is
+// empty.  Same two device functions as the round kernels, hence the same results.
+template <int PRIM, bool NEE, bool COUNT>
+__global__ __launch_bounds__(kTraceBlock) void k_tail(DevScene S, PathState P, const uint32_t* __restrict__ queue,
+                                                      const uint32_t* __restrict__ qn, uint32_t* __restrict__ cursor, uint32_t depth,
+                                                      uint32_t k0, uint32_t k1, LaunchCfg cfg, unsigned long long* counters) {
+    __shared__ unsigned long long smem[kLdsStack * kTraceBlock];
+    LaneStack stk = make_stack(smem, cfg);
+    const uint32_t n = *qn;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t nn = 0, np = 0, worst = 0, rays = 0;
+    uint32_t slot = 0;
+    bool alive = false, drained = false;
+    while (true) {
+        // refill: lanes without a path take consecutive queue entries
+        const unsigned long long want = __ballot(!alive && !drained);
+        if (want) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(cursor, (uint32_t)__popcll(want));
+            base = __shfl(base, 0, 64);
+            if (!alive && !drained) {
+                const uint32_t idx = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
+                if (idx < n) {
+                    slot = queue[idx];
+                    alive = true;
+                } else {
+                    drained = true;
+                }
+            }
+        }
+        if (__ballot(alive) == 0) break;
+        if (alive) {
+            const float4 ro = P.ro[slot], rd = P.rd[slot];
+            float dist = ro.w;
+            Hit h;
+            const uint32_t nn0 = nn;
+            traverse<PRIM, false, COUNT>(S, xyz(ro), xyz(rd), dist, h, stk, nn, np);
+            if (COUNT) worst = nn - nn0 > worst ? nn - nn0 : worst;
+            rays += 1;
+            const uint32_t bits = h.slot == PT_MISS ? PT_MISS : (h.slot | (h.inside << 31));
+            P.hit[slot] = make_float4(__uint_as_float(bits), dist, h.u, h.v);
+            alive = shade_one<PRIM, NEE>(S, P, slot, depth, k0, k1, stk, counters);
+        }
+    }
+    wave_add(counters + CNT_RAYS_CLOSEST, rays);
+    wave_add(counters + CNT_TAIL_RAYS, rays);
+    if (COUNT) {
+        wave_add(counters + CNT_TAIL_NODE_TESTS, nn);
+        wave_add(counters + CNT_TAIL_PRIM_TESTS, np);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t other = __shfl_down(worst, off, 64);
+            worst = other > worst ? other : worst;
+        }
+        if ((threadIdx.x & 63) == 0 && worst) atomicMax(counters + CNT_MAX_NODE_TESTS, (unsigned long long)worst);
+    }
+}
+
 // chunk[idx] += sample, src/main.rs:159 — samples of one pixel are added in sample order, so the
 // sum is the one the reference's frame loop builds one frame at a time.
 __global__ __launch_bounds__(256) void k_accumulate(PixelMap M, const float4* __restrict__ out, uint32_t n_samples, float* __restrict__ accum) {
@@ -720,8 +795,9 @@ void launch_focus(int prim, const DevScene& S, DevCamera* cam, const LaunchCfg& 
 void launch_raygen(const DevCamera* cam, const PixelMap& M, const PathState& P, uint32_t n_samples, uint32_t sample_base, uint32_t k0,
                    uint32_t k1, bool nee, uint32_t* queue, uint32_t* qn, unsigned long long* counters, hipStream_t st) {
     const uint64_t total = (uint64_t)n_samples * M.npix_pad;
+    const int identity = (M.width % M.tile == 0 && M.height % M.tile == 0) ? 1 : 0;
     hipLaunchKernelGGL(k_raygen, dim3(blocks_for(total, 256, 8192)), dim3(256), 0, st, cam, M, P, n_samples, sample_base, k0, k1,
-                       nee ? 1 : 0, queue, qn, counters);
+                       nee ? 1 : 0, identity, queue, qn, counters);
 }
 
 void launch_extend(int prim, bool count, const DevScene& S, const PathState& P, const uint32_t* queue, const uint32_t* qn,
@@ -741,6 +817,22 @@ void launch_shade(int prim, bool nee, const DevScene& S, const PathState& P, con
     if (prim == PRIM_TRIANGLE) { if (nee) PT_SH(PRIM_TRIANGLE, true); else PT_SH(PRIM_TRIANGLE, false); }
     else { if (nee) PT_SH(PRIM_SPHERE, true); else PT_SH(PRIM_SPHERE, false); }
 #undef PT_SH
+}
+
+void launch_tail(int prim, bool nee, bool count, const DevScene& S, const PathState& P, const uint32_t* queue, const uint32_t* qn,
+                 uint32_t* cursor, uint32_t n_hint, uint32_t depth, uint32_t k0, uint32_t k1, const LaunchCfg& cfg,
+                 unsigned long long* counters, hipStream_t st) {
+    // persistent: about a quarter of the paths get a lane at once, the rest are fetched as lanes free up
+    const uint32_t grid = blocks_for(n_hint, kTraceBlock, cfg.grid);  // n_hint lanes; further paths are fetched as lanes free up
+#define PT_TAIL(PR, N, C) hipLaunchKernelGGL((k_tail<PR, N, C>), dim3(grid), dim3(kTraceBlock), 0, st, S, P, queue, qn, cursor, depth, k0, k1, cfg, counters)
+    if (prim == PRIM_TRIANGLE) {
+        if (nee) { if (count) PT_TAIL(PRIM_TRIANGLE, true, true); else PT_TAIL(PRIM_TRIANGLE, true, false); }
+        else { if (count) PT_TAIL(PRIM_TRIANGLE, false, true); else PT_TAIL(PRIM_TRIANGLE, false, false); }
+    } else {
+        if (nee) { if (count) PT_TAIL(PRIM_SPHERE, true, true); else PT_TAIL(PRIM_SPHERE, true, false); }
+        else { if (count) PT_TAIL(PRIM_SPHERE, false, true); else PT_TAIL(PRIM_SPHERE, false, false); }
+    }
+#undef PT_TAIL
 }
 
 void launch_accumulate(const PixelMap& M, const float4* out, uint32_t n_samples, float* accum, hipStream_t st) {

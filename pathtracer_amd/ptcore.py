@@ -32,12 +32,13 @@ PT_OK = 0
 PT_ERR_INVALID, PT_ERR_STATE, PT_ERR_NO_DEVICE, PT_ERR_HIP, PT_ERR_LIMIT, PT_ERR_BVH = -1, -2, -3, -4, -5, -6
 SHARD_ALL, SHARD_TILES = 0, 1
 RENDER_TIMED, RENDER_COUNT = 1, 2
+OPT_BATCH_PATHS, OPT_LANES, OPT_TAIL_MIN_PATHS, OPT_TAIL_FRACTION, OPT_TAIL_STREAMS, OPT_TAIL_PATHS_PER_LANE = 0, 1, 2, 3, 4, 5
 
 EXPORTS = [
     "pt_strerror", "pt_last_error", "pt_create", "pt_destroy", "pt_set_triangles", "pt_set_spheres", "pt_set_materials",
     "pt_set_sky", "pt_build", "pt_set_bvh", "pt_bvh_build", "pt_get_bvh_sizes", "pt_get_bvh", "pt_set_camera", "pt_get_camera", "pt_generate", "pt_render",
     "pt_reset_accum", "pt_read_accum", "pt_read_rgb8", "pt_accum_device_ptr", "pt_add_external_samples", "pt_trace",
-    "pt_sample_skybox", "pt_get_counters", "pt_reset_counters",
+    "pt_sample_skybox", "pt_set_option", "pt_get_counters", "pt_get_round_stats", "pt_reset_counters",
 ]
 
 
@@ -62,7 +63,9 @@ class Shard(C.Structure):
 class Counters(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("rays_closest", C.c_uint64), ("rays_any", C.c_uint64),
                 ("node_tests", C.c_uint64), ("prim_tests", C.c_uint64), ("extend_launches", C.c_uint64),
-                ("extend_ms", C.c_double), ("render_ms", C.c_double)]
+                ("extend_ms", C.c_double), ("render_ms", C.c_double), ("tail_rays", C.c_uint64),
+                ("tail_node_tests", C.c_uint64), ("tail_prim_tests", C.c_uint64), ("tail_launches", C.c_uint64),
+                ("tail_ms", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -261,6 +264,9 @@ class PathTracer:
         self._ck(self.l.pt_sample_skybox(self.h, _ptr(dirs), C.c_uint64(len(dirs)), _ptr(out)))
         return out
 
+    def set_option(self, option, value):
+        self._ck(self.l.pt_set_option(self.h, C.c_int(option), C.c_uint64(value)))
+
     def counters(self):
         c = Counters()
         self._ck(self.l.pt_get_counters(self.h, C.byref(c)))
@@ -268,6 +274,12 @@ class PathTracer:
 
     def reset_counters(self):
         self._ck(self.l.pt_reset_counters(self.h))
+
+    def round_stats(self):
+        sizes = np.zeros(4096, np.uint32)
+        n, worst = C.c_uint32(), C.c_uint64()
+        self._ck(self.l.pt_get_round_stats(self.h, _ptr(sizes), C.c_uint32(len(sizes)), C.byref(n), C.byref(worst)))
+        return sizes[: n.value].copy(), worst.value
 
 
 class AccumView:

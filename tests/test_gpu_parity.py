@@ -332,3 +332,39 @@ def test_host_built_tree_is_adopted(ptcore, pairs, sky):
     with pytest.raises(ptcore.PtError):
         g.set_bvh(bad, idx)
     g.close()
+
+
+@pytest.mark.parametrize("name", ["cube", "spheres", "mesh_20k"])
+def test_scheduling_does_not_change_results(ptcore, pairs, name):
+    """Batch size, number of batches in flight and the hand-over to the fused tail kernel are
+    scheduling choices: every combination must give the oracle's sums bit for bit."""
+    g, o, scene, cam_o, cam_t = pairs[name]
+    W, H, spp = 72, 40, 6
+    o.set_camera(cam_o, cam_t, W, H)
+    o.render(spp, 32, seed=21, nee_mode=1)
+    want = o.read_accum()[0]
+    orays = None
+    configs = [
+        dict(batch=W * H, lanes=4, tail_min=0, tail_frac=0),          # 6 batches, wavefront rounds only
+        dict(batch=2 * W * H, lanes=2, tail_min=1 << 30, tail_frac=1),  # tail kernel takes over after 3 rounds
+        dict(batch=W * H, lanes=3, tail_min=64, tail_frac=8),
+        dict(batch=1 << 23, lanes=1, tail_min=65536, tail_frac=16),    # defaults
+    ]
+    try:
+        for cfg in configs:
+            g.set_option(ptcore.OPT_BATCH_PATHS, cfg["batch"])
+            g.set_option(ptcore.OPT_LANES, cfg["lanes"])
+            g.set_option(ptcore.OPT_TAIL_MIN_PATHS, cfg["tail_min"])
+            g.set_option(ptcore.OPT_TAIL_FRACTION, cfg["tail_frac"])
+            g.set_camera(cam_o, cam_t, W, H)
+            g.reset_counters()
+            g.render(spp, 32, seed=21)
+            assert g.read_accum()[0].tobytes() == want.tobytes(), cfg
+            rays = g.counters()["rays_closest"]
+            orays = orays or rays
+            assert rays == orays, cfg
+    finally:
+        g.set_option(ptcore.OPT_BATCH_PATHS, 1 << 23)
+        g.set_option(ptcore.OPT_LANES, 8)
+        g.set_option(ptcore.OPT_TAIL_MIN_PATHS, 65536)
+        g.set_option(ptcore.OPT_TAIL_FRACTION, 32)
