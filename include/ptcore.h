@@ -164,6 +164,11 @@ int pt_generate(pt_ctx *ctx, const uint32_t *xy, uint64_t n, uint32_t sample, ui
  * src/main.rs:159.  shard may be NULL (= PT_SHARD_ALL, sample_begin = samples rendered so far). */
 int pt_render(pt_ctx *ctx, uint32_t spp, uint32_t max_depth, uint64_t seed, const pt_shard *shard,
               uint32_t flags);
+/* The pixels a shard owns, in the order the device walks them (device-free; the same mapping
+ * function is compiled into the kernels).  xy: up to cap (x, y) pairs; n_out: pixels owned.
+ * tile = 8 with nranks = 1 is the PT_SHARD_ALL order. */
+int pt_shard_map(uint32_t width, uint32_t height, uint32_t tile, uint32_t rank, uint32_t nranks, uint32_t *xy,
+                 uint64_t cap, uint64_t *n_out);
 int pt_reset_accum(pt_ctx *ctx);
 /* accum: W x H x 3 floats, the running SUM (src/main.rs:100,159); spp_out: samples summed. */
 int pt_read_accum(pt_ctx *ctx, float *rgb, float *spp_out);

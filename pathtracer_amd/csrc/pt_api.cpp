@@ -13,6 +13,7 @@
 
 #include "../../include/ptcore.h"
 #include "pt_bvh.h"
+#include "pt_device.h"
 #include "pt_kernels.h"
 
 using namespace pt;
@@ -708,11 +709,7 @@ int pt_render(pt_ctx* c, uint32_t spp, uint32_t max_depth, uint64_t seed, const 
             return c->fail(PT_ERR_INVALID, "pt_render: unknown shard kind");
         }
     }
-    M.tiles_x = (M.width + M.tile - 1) / M.tile;
-    M.tiles_y = (M.height + M.tile - 1) / M.tile;
-    const uint32_t n_tiles = M.tiles_x * M.tiles_y;
-    M.n_local_tiles = n_tiles > M.rank ? (n_tiles - M.rank + M.nranks - 1) / M.nranks : 0;
-    M.npix_pad = M.n_local_tiles * M.tile * M.tile;
+    pixelmap_init(M, M.width, M.height, M.tile, M.rank, M.nranks);
     if (M.npix_pad == 0) {  // this rank owns no tile
         c->spp += (float)spp;
         c->samples_done = sample_begin + spp;
@@ -912,6 +909,25 @@ int pt_set_option(pt_ctx* c, int option, uint64_t value) {
         case PT_OPT_TAIL_PATHS_PER_LANE: c->opt_tail_paths_per_lane = std::max<uint64_t>(value, 1); return PT_OK;
         default: return c->fail(PT_ERR_INVALID, "pt_set_option: unknown option");
     }
+}
+
+int pt_shard_map(uint32_t width, uint32_t height, uint32_t tile, uint32_t rank, uint32_t nranks, uint32_t* xy, uint64_t cap,
+                 uint64_t* n_out) {
+    if (width == 0 || height == 0 || tile == 0 || tile % 8 != 0 || tile > 1024 || nranks == 0 || rank >= nranks) return PT_ERR_INVALID;
+    PixelMap M{};
+    pixelmap_init(M, width, height, tile, rank, nranks);
+    uint64_t n = 0;
+    for (uint32_t idx = 0; idx < M.npix_pad; ++idx) {
+        uint32_t x, y;
+        if (!map_pixel(M, idx, &x, &y)) continue;
+        if (xy && n < cap) {
+            xy[2 * n] = x;
+            xy[2 * n + 1] = y;
+        }
+        n += 1;
+    }
+    if (n_out) *n_out = n;
+    return PT_OK;
 }
 
 int pt_reset_counters(pt_ctx* c) {

@@ -10,6 +10,7 @@
 
 #include "../../include/ptcore.h"
 #include "../../include/ptcore_detmath.h"
+#include "pt_pixelmap.h"
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -197,5 +198,21 @@ PT_DEV uint8_t tonemap_channel(float c) {
     if (v != v || v <= 0.0f) return 0;
     return (uint8_t)v;
 }
+
+// slot index inside one sample -> pixel
+PT_DEV bool map_pixel(const PixelMap& M, uint32_t idx, uint32_t* x_out, uint32_t* y_out) {
+    const uint32_t per_tile = M.tile * M.tile;
+    const uint32_t local_tile = idx / per_tile, within = idx % per_tile;
+    const uint32_t T = local_tile * M.nranks + M.rank;
+    const uint32_t tx = T % M.tiles_x, ty = T / M.tiles_x;
+    const uint32_t sub = within >> 6, lane = within & 63u;
+    const uint32_t subs = M.tile >> 3;
+    const uint32_t x = tx * M.tile + (sub % subs) * 8 + (lane & 7u);
+    const uint32_t y = ty * M.tile + (sub / subs) * 8 + (lane >> 3);
+    *x_out = x;
+    *y_out = y;
+    return x < M.width && y < M.height;
+}
+
 
 }  // namespace pt

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "../../include/ptcore.h"
+#include "pt_pixelmap.h"
 
 namespace pt {
 
@@ -33,17 +34,6 @@ struct DevCamera {
     float origin[3], p1[3], p2[3], p3[3], right[3], up[3], direction[3], target[3];
     float focal_distance, lens_size;
     uint32_t width, height;
-};
-
-// slot -> pixel mapping of one render call: 8x8 pixel tiles per wave for coherent primary rays,
-// grouped in `tile` x `tile` blocks that are dealt round-robin to ranks.
-struct PixelMap {
-    uint32_t width, height;
-    uint32_t tile;        // edge of a rank tile (multiple of 8)
-    uint32_t tiles_x, tiles_y;
-    uint32_t rank, nranks;
-    uint32_t n_local_tiles;
-    uint32_t npix_pad;    // n_local_tiles * tile * tile
 };
 
 // Per-path state, structure of float4 arrays indexed by slot = s_local * npix_pad + idx.

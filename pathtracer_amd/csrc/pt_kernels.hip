@@ -232,22 +232,6 @@ __device__ __forceinline__ V3 sky_lookup(const DevScene& S, V3 d) {
     return V3{p[0], p[1], p[2]};
 }
 
-// slot index inside one sample -> pixel
-__device__ __forceinline__ bool map_pixel(const PixelMap& M, uint32_t idx, uint32_t* x_out, uint32_t* y_out) {
-    const uint32_t per_tile = M.tile * M.tile;
-    const uint32_t local_tile = idx / per_tile, within = idx % per_tile;
-    const uint32_t T = local_tile * M.nranks + M.rank;
-    const uint32_t tx = T % M.tiles_x, ty = T / M.tiles_x;
-    const uint32_t sub = within >> 6, lane = within & 63u;
-    const uint32_t subs = M.tile >> 3;
-    const uint32_t x = tx * M.tile + (sub % subs) * 8 + (lane & 7u);
-    const uint32_t y = ty * M.tile + (sub / subs) * 8 + (lane >> 3);
-    *x_out = x;
-    *y_out = y;
-    return x < M.width && y < M.height;
-}
-
-
 // Camera::generate, src/camera.rs:426-449
 __device__ __forceinline__ void generate_ray(const DevCamera& cam, uint32_t x, uint32_t y, uint32_t sample, uint32_t k0, uint32_t k1,
                                              V3* o_out, V3* d_out) {

@@ -1,0 +1,96 @@
+// render_main.cpp — src/main.rs without SDL: builds a scene, runs the progressive frame loop on the
+// GPU through the C ABI and writes the tonemapped frame as a PPM.
+//   render [--spheres | --cube] [--size WxH] [--frames N] [--spp-per-frame K] [--sky file.raw] [--out frame.ppm]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "pathtracer.hpp"
+
+using namespace pt;
+
+// stand-in for assets/sky_15.raw (absent from the reference checkout): vertical gradient + horizon band
+static std::vector<float> synthetic_sky() {
+    std::vector<float> sky((size_t)2500 * 1250 * 3);
+    for (int v = 0; v < 1250; ++v) {
+        float t = (v + 0.5f) / 1250.0f;
+        float up = t < 0.5f ? t / 0.5f : 1.0f, dn = t < 0.5f ? 0.0f : (t - 0.5f) / 0.5f;
+        float band = 0.6f * std::exp(-((t - 0.5f) / 0.03f) * ((t - 0.5f) / 0.03f));
+        float r = (t < 0.5f ? 0.25f + 0.85f * up * up : 1.10f - 0.92f * std::sqrt(dn)) + band;
+        float g = (t < 0.5f ? 0.45f + 0.55f * up * up : 1.00f - 0.84f * std::sqrt(dn)) + 0.9f * band;
+        float b = (t < 0.5f ? 0.95f - 0.10f * up * up : 0.85f - 0.71f * std::sqrt(dn)) + 0.7f * band;
+        for (int u = 0; u < 2500; ++u) {
+            float* p = &sky[((size_t)v * 2500 + u) * 3];
+            p[0] = r; p[1] = g; p[2] = b;
+        }
+    }
+    return sky;
+}
+
+static std::vector<Triangle> cube_mesh(Material m) {
+    const float h = 0.3f, cx = 0.7f, cz = 0.6f, y0 = -0.3f, y1 = 0.3f;
+    Vec3 v[8] = {{cx - h, y0, cz - h}, {cx + h, y0, cz - h}, {cx + h, y1, cz - h}, {cx - h, y1, cz - h},
+                 {cx - h, y0, cz + h}, {cx + h, y0, cz + h}, {cx + h, y1, cz + h}, {cx - h, y1, cz + h}};
+    int quads[6][4] = {{0, 3, 2, 1}, {4, 5, 6, 7}, {0, 4, 7, 3}, {1, 2, 6, 5}, {3, 7, 6, 2}, {0, 1, 5, 4}};
+    Vec3 normals[6] = {{0, 0, -1}, {0, 0, 1}, {-1, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, -1, 0}};
+    std::vector<Triangle> out;
+    for (int q = 0; q < 6; ++q) {
+        const int* k = quads[q];
+        out.push_back({v[k[0]], v[k[1]], v[k[2]], normals[q], normals[q], normals[q], m});
+        out.push_back({v[k[0]], v[k[2]], v[k[3]], normals[q], normals[q], normals[q], m});
+    }
+    return out;
+}
+
+template <class T>
+static int run(Camera<T>& camera, uint32_t W, uint32_t H, int frames, int spp, const std::string& out) {
+    std::vector<uint8_t> fb((size_t)W * H * 3);
+    auto t0 = std::chrono::steady_clock::now();
+    for (int f = 0; f < frames; ++f) {
+        camera.render(spp, 32, 2026);   // spp += 1 per frame in the reference, main.rs:143
+        camera.rgb24(fb.data(), (size_t)W * 3);
+    }
+    double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    pt_counters c = camera.counters();
+    std::printf("%d frames x %d spp: %.1f ms/frame, %.1f Mrays/s, %.1f Mpaths/s, focal distance %g\n", frames, spp, dt * 1e3 / frames,
+                c.rays_closest / dt / 1e6, c.paths / dt / 1e6, camera.state().focal_distance);
+    FILE* f = std::fopen(out.c_str(), "wb");
+    if (!f) return 1;
+    std::fprintf(f, "P6\n%u %u\n255\n", W, H);
+    std::fwrite(fb.data(), 1, fb.size(), f);
+    std::fclose(f);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    uint32_t W = 800, H = 600;  // main.rs:77-78
+    int frames = 16, spp = 1;
+    bool spheres = false;
+    std::string out = "frame.ppm", sky_path;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        if (a == "--spheres") spheres = true;
+        else if (a == "--cube") spheres = false;
+        else if (a == "--size" && i + 1 < argc) std::sscanf(argv[++i], "%ux%u", &W, &H);
+        else if (a == "--frames" && i + 1 < argc) frames = std::atoi(argv[++i]);
+        else if (a == "--spp-per-frame" && i + 1 < argc) spp = std::atoi(argv[++i]);
+        else if (a == "--sky" && i + 1 < argc) sky_path = argv[++i];
+        else if (a == "--out" && i + 1 < argc) out = argv[++i];
+        else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
+    }
+    try {
+        std::vector<float> sky = sky_path.empty() ? synthetic_sky() : Scene<Sphere>::read_skybox(sky_path);
+        if (spheres) {
+            Camera<Sphere> camera(W, H, Scene<Sphere>::default_scene(std::move(sky)));
+            camera.look_at({0.0f, 0.2f, 1.0f}, {0.0f, -0.2f, -2.0f});  // the default pose looks away from the spheres
+            return run(camera, W, H, frames, spp, out);
+        }
+        Camera<Triangle> camera(W, H, Scene<Triangle>::scene(cube_mesh(Material::dielectric(1.0f, 1.5f, {0.01f, 0.9f, 0.01f})), std::move(sky), 0.0f));
+        return run(camera, W, H, frames, spp, out);
+    } catch (const Error& e) {
+        std::fprintf(stderr, "error %d: %s\n", e.status, e.what());
+        return 1;
+    }
+}

@@ -37,7 +37,7 @@ OPT_BATCH_PATHS, OPT_LANES, OPT_TAIL_MIN_PATHS, OPT_TAIL_FRACTION, OPT_TAIL_STRE
 EXPORTS = [
     "pt_strerror", "pt_last_error", "pt_create", "pt_destroy", "pt_set_triangles", "pt_set_spheres", "pt_set_materials",
     "pt_set_sky", "pt_build", "pt_set_bvh", "pt_bvh_build", "pt_get_bvh_sizes", "pt_get_bvh", "pt_set_camera", "pt_get_camera", "pt_generate", "pt_render",
-    "pt_reset_accum", "pt_read_accum", "pt_read_rgb8", "pt_accum_device_ptr", "pt_add_external_samples", "pt_trace",
+    "pt_shard_map", "pt_reset_accum", "pt_read_accum", "pt_read_rgb8", "pt_accum_device_ptr", "pt_add_external_samples", "pt_trace",
     "pt_sample_skybox", "pt_set_option", "pt_get_counters", "pt_get_round_stats", "pt_reset_counters",
 ]
 
@@ -123,6 +123,20 @@ def bvh_build_host(geom, prim_kind=0):
     if rc != PT_OK:
         raise PtError(rc, lib.pt_strerror(rc).decode())
     return nodes[: nn.value].copy(), idx, depth.value
+
+
+def shard_map(width, height, tile=8, rank=0, nranks=1):
+    """(n, 2) uint32 pixel coordinates owned by a shard, in device order (pt_shard_map, no device)."""
+    lib = load()
+    n = C.c_uint64()
+    rc = lib.pt_shard_map(C.c_uint32(width), C.c_uint32(height), C.c_uint32(tile), C.c_uint32(rank), C.c_uint32(nranks),
+                          None, C.c_uint64(0), C.byref(n))
+    if rc != PT_OK:
+        raise PtError(rc, lib.pt_strerror(rc).decode())
+    xy = np.zeros((n.value, 2), dtype=np.uint32)
+    lib.pt_shard_map(C.c_uint32(width), C.c_uint32(height), C.c_uint32(tile), C.c_uint32(rank), C.c_uint32(nranks),
+                     _ptr(xy), C.c_uint64(n.value), C.byref(n))
+    return xy
 
 
 class PathTracer:
