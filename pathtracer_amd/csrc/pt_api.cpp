@@ -36,7 +36,7 @@ constexpr uint64_t kTargetSlots = 8u << 20;    // paths kept in flight per batch
 constexpr uint64_t kMaxSlots = 1ull << 31;
 constexpr uint32_t kMaxLanes = 8;              // batches in flight (one HIP stream + path-state set each)
 constexpr uint64_t kTailMinPaths = 65536;      // hand a batch to the fused tail kernel below this many live paths ...
-constexpr uint64_t kTailFraction = 32;         // ... or below 1/32 of the batch
+constexpr uint64_t kTailFraction = 16;         // ... or below 1/16 of the batch
 
 // One batch in flight.
 struct RenderLane {
@@ -96,7 +96,7 @@ struct pt_ctx {
     DevBuf d_counters;
     double extend_ms = 0, render_ms = 0, tail_ms = 0;
     uint64_t extend_launches = 0, tail_launches = 0;
-    uint64_t opt_batch_slots = kTargetSlots, opt_tail_min = kTailMinPaths, opt_tail_fraction = kTailFraction, opt_lanes = kMaxLanes, opt_tail_streams = 4, opt_tail_paths_per_lane = 2;
+    uint64_t opt_batch_slots = kTargetSlots, opt_tail_min = kTailMinPaths, opt_tail_fraction = kTailFraction, opt_lanes = kMaxLanes, opt_tail_streams = 4, opt_tail_paths_per_lane = 2, opt_simple_extend = 0;
     std::vector<uint32_t> round_sizes;  // queue length of every round of the last finished batch
 
     int fail(int code, const std::string& msg) {
@@ -577,8 +577,8 @@ static int lane_alloc(pt_ctx* c, RenderLane& L, uint64_t slots, uint32_t rounds)
     }
     if (c->nee && L.d_acc.bytes < slots * 16)
         if ((rc = dev_alloc(c, L.d_acc, slots * 16))) return rc;
-    if (rounds + 2 > L.qn_len) {
-        if ((rc = dev_alloc(c, L.d_qn, (size_t)(rounds + 2) * 4))) return rc;
+    if (rounds + 2 > L.qn_len) {  // queue lengths [0, rounds+2) then one fetch cursor per round
+        if ((rc = dev_alloc(c, L.d_qn, (size_t)(rounds + 2) * 8))) return rc;
         L.qn_len = rounds + 2;
     }
     if (!L.d_spill.p || L.d_spill.bytes < c->spill_bytes)
@@ -615,12 +615,12 @@ static int lane_issue_rounds(pt_ctx* c, RenderLane& L, const RenderJob& J, uint3
             PT_HIP(c, hipEventCreate(&a));
             PT_HIP(c, hipEventCreate(&b));
             PT_HIP(c, hipEventRecord(a, L.stream));
-            launch_extend(c->prim_kind, J.count, c->ds, L.ps, q[r & 1], qn + r, L.cfg, counters, L.stream);
+            launch_extend(c->prim_kind, J.count, c->opt_simple_extend != 0, c->ds, L.ps, q[r & 1], qn + r, qn + J.rounds + 2 + r, L.cfg, counters, L.stream);
             PT_HIP(c, hipEventRecord(b, L.stream));
             c->ext_events.push_back(a);
             c->ext_events.push_back(b);
         } else {
-            launch_extend(c->prim_kind, J.count, c->ds, L.ps, q[r & 1], qn + r, L.cfg, counters, L.stream);
+            launch_extend(c->prim_kind, J.count, c->opt_simple_extend != 0, c->ds, L.ps, q[r & 1], qn + r, qn + J.rounds + 2 + r, L.cfg, counters, L.stream);
         }
         c->extend_launches += 1;
         launch_shade(c->prim_kind, c->nee, c->ds, L.ps, J.M, q[r & 1], qn + r, q[(r + 1) & 1], qn + r + 1, J.max_depth, L.sample_base,
@@ -640,7 +640,7 @@ static int lane_start(pt_ctx* c, RenderLane& L, const RenderJob& J, uint32_t bat
     L.sample_base = sample_base;
     L.round = 0;
     L.state = RenderLane::RUNNING;
-    PT_HIP(c, hipMemsetAsync(qn, 0, (size_t)(J.rounds + 2) * 4, L.stream));
+    PT_HIP(c, hipMemsetAsync(qn, 0, (size_t)(J.rounds + 2) * 8, L.stream));
     launch_raygen((const DevCamera*)c->d_cam.p, J.M, L.ps, ns, sample_base, J.k0, J.k1, c->nee, (uint32_t*)L.d_q0.p, qn,
                   (unsigned long long*)c->d_counters.p, L.stream);
     if (J.max_depth == 0)  // `for _ in 0..0` never runs: every sample is (0,0,0)
@@ -663,7 +663,7 @@ static int lane_finish(pt_ctx* c, RenderLane& L, const RenderJob& J, uint32_t li
             PT_HIP(c, hipEventRecord(a, ts));
         }
         launch_tail(c->prim_kind, c->nee, J.count, c->ds, L.ps, (L.round & 1) ? (uint32_t*)L.d_q1.p : (uint32_t*)L.d_q0.p, qn + L.round,
-                    qn + J.rounds + 1, (uint32_t)((live + c->opt_tail_paths_per_lane - 1) / c->opt_tail_paths_per_lane), J.max_depth, J.k0, J.k1, L.cfg, (unsigned long long*)c->d_counters.p, ts);
+                    qn + 2 * J.rounds + 3, (uint32_t)((live + c->opt_tail_paths_per_lane - 1) / c->opt_tail_paths_per_lane), J.max_depth, J.k0, J.k1, L.cfg, (unsigned long long*)c->d_counters.p, ts);
         if (J.timed) {
             PT_HIP(c, hipEventRecord(b, ts));
             c->tail_events.push_back(a);
@@ -906,6 +906,7 @@ int pt_set_option(pt_ctx* c, int option, uint64_t value) {
         case PT_OPT_TAIL_MIN_PATHS: c->opt_tail_min = value; return PT_OK;
         case PT_OPT_TAIL_FRACTION: c->opt_tail_fraction = value; return PT_OK;
         case PT_OPT_TAIL_STREAMS: c->opt_tail_streams = std::min<uint64_t>(std::max<uint64_t>(value, 1), 4); return PT_OK;
+        case PT_OPT_SIMPLE_EXTEND: c->opt_simple_extend = value; return PT_OK;
         case PT_OPT_TAIL_PATHS_PER_LANE: c->opt_tail_paths_per_lane = std::max<uint64_t>(value, 1); return PT_OK;
         default: return c->fail(PT_ERR_INVALID, "pt_set_option: unknown option");
     }

@@ -71,8 +71,8 @@ void launch_focus(int prim, const DevScene& S, DevCamera* cam, const LaunchCfg& 
 // the wavefront pipeline
 void launch_raygen(const DevCamera* cam, const PixelMap& M, const PathState& P, uint32_t n_samples, uint32_t sample_base, uint32_t k0,
                    uint32_t k1, bool nee, uint32_t* queue, uint32_t* qn, unsigned long long* counters, hipStream_t st);
-void launch_extend(int prim, bool count, const DevScene& S, const PathState& P, const uint32_t* queue, const uint32_t* qn,
-                   const LaunchCfg& cfg, unsigned long long* counters, hipStream_t st);
+void launch_extend(int prim, bool count, bool simple, const DevScene& S, const PathState& P, const uint32_t* queue, const uint32_t* qn,
+                   uint32_t* cursor, const LaunchCfg& cfg, unsigned long long* counters, hipStream_t st);
 void launch_shade(int prim, bool nee, const DevScene& S, const PathState& P, const PixelMap& M, const uint32_t* q_in, const uint32_t* qn_in,
                   uint32_t* q_out, uint32_t* qn_out, uint32_t depth, uint32_t sample_base, uint32_t k0, uint32_t k1,
                   const LaunchCfg& cfg, unsigned long long* counters, hipStream_t st);

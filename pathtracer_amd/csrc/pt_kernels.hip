@@ -419,6 +419,192 @@ __global__ __launch_bounds__(kTraceBlock) void k_extend(DevScene S, PathState P,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_extend_pw — the production traversal kernel: persistent waves, per-lane ray refill, while-while.
+//
+// With one ray per lane and no refill, a wave lives as long as its longest ray (60-100 loop
+// iterations for a mean of ~10), so most lanes idle.  Here every lane owns a small traversal state
+// machine; when at least kRefillLanes lanes of the wave are idle they take the next rays from the
+// queue with one wave-aggregated atomic.  Each outer iteration runs an "internal" phase (lanes at
+// internal nodes step until at most a quarter of the wave is still descending) and a "leaf" phase
+// (lanes at leaves test their primitives, then pop).  A lane only ever waits — its own sequence of
+// node visits, primitive tests and ray.distance updates is exactly the one of traverse<>, so the
+// results are identical.
+struct LaneTrav {
+    V3 o, d, rcp;
+    float dist;
+    uint32_t cur, sp;
+    uint32_t hslot, hinside;
+    float hu, hv;
+    uint32_t slot;  // path slot the ray belongs to
+};
+
+// pop the next node still reachable with the current ray.distance (bvh.rs:194-196); false = stack empty
+__device__ __forceinline__ bool lane_pop(LaneTrav& T, const LaneStack& stk) {
+    while (T.sp != 0) {
+        T.sp -= 1;
+        uint32_t ref;
+        float tpush;
+        stk.get(T.sp, &ref, &tpush);
+        if (!(T.dist < tpush)) {
+            T.cur = ref;
+            return true;
+        }
+    }
+    return false;
+}
+
+constexpr int kRefillLanes = 20;     // refill when at least this many lanes of the wave are idle
+constexpr int kFetchChunk = 256;     // rays a wave reserves per atomic on the queue cursor
+
+template <int PRIM, bool COUNT>
+__global__ __launch_bounds__(kTraceBlock) void k_extend_pw(DevScene S, PathState P, const uint32_t* __restrict__ queue,
+                                                           const uint32_t* __restrict__ qn, uint32_t* __restrict__ cursor, LaunchCfg cfg,
+                                                           unsigned long long* counters) {
+    __shared__ unsigned long long smem[kLdsStack * kTraceBlock];
+    LaneStack stk = make_stack(smem, cfg);
+    const uint32_t n = *qn;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t nn = 0, np = 0, worst = 0, mine = 0;
+    LaneTrav T;
+    T.cur = 0; T.sp = 0; T.dist = 0.f; T.hslot = PT_MISS; T.hinside = 0; T.hu = T.hv = 0.f; T.slot = 0;
+    T.o = T.d = T.rcp = V3{0.f, 0.f, 0.f};
+    bool active = false;
+    bool drained = false;  // wave-uniform: the queue has no more rays for this wave
+    uint32_t chunk_next = 0, chunk_end = 0;  // wave-uniform: this wave's current piece of the queue
+    // rays reserved per atomic: large queues take kFetchChunk at a time (few atomics on one address),
+    // small ones are spread over all waves of the grid
+    const uint32_t per_wave = n / (gridDim.x * (kTraceBlock / 64)) + 1;
+    const uint32_t chunk = per_wave >= (uint32_t)kFetchChunk ? (uint32_t)kFetchChunk : (per_wave < 32u ? 32u : per_wave);
+    while (true) {
+        const unsigned long long idle = __ballot(!active);
+        const int n_idle = __popcll(idle);
+        if (!drained && (n_idle >= kRefillLanes)) {
+            if (chunk_next >= chunk_end) {  // wave-uniform: take the next kFetchChunk rays of the queue (one atomic)
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(cursor, chunk);
+                base = __builtin_amdgcn_readfirstlane(__shfl(base, 0, 64));
+                chunk_next = base;
+                chunk_end = base + chunk < n ? base + chunk : n;
+                if (base >= n) {
+                    drained = true;
+                    chunk_next = chunk_end = 0;
+                }
+            }
+            if (!active && !drained) {
+                const uint32_t idx = chunk_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                if (idx < chunk_end) {
+                    T.slot = queue[idx];
+                    const float4 ro = P.ro[T.slot], rd = P.rd[T.slot];
+                    T.o = xyz(ro);
+                    T.d = xyz(rd);
+                    T.rcp = V3{1.0f / T.d.x, 1.0f / T.d.y, 1.0f / T.d.z};
+                    T.dist = ro.w;
+                    T.hslot = PT_MISS;
+                    T.hinside = 0;
+                    T.hu = T.hv = 0.f;
+                    T.sp = 0;
+                    float tmin;
+                    if (COUNT) { nn += 1; mine = 1; }
+                    if (slab(S.root_min[0], S.root_min[1], S.root_min[2], S.root_max[0], S.root_max[1], S.root_max[2], T.o, T.rcp, T.dist, &tmin)) {
+                        T.cur = S.root_ref;
+                        active = true;
+                    } else {
+                        P.hit[T.slot] = make_float4(__uint_as_float(PT_MISS), T.dist, 0.f, 0.f);
+                    }
+                }
+            }
+            chunk_next = chunk_next + (uint32_t)n_idle < chunk_end ? chunk_next + (uint32_t)n_idle : chunk_end;
+        }
+        const unsigned long long act = __ballot(active);
+        if (act == 0) {
+            if (drained) break;
+            continue;
+        }
+        // ---- internal phase
+        const int n_act = __popcll(act);
+        while (true) {
+            const bool at_internal = active && !(T.cur & kLeafBit);
+            const unsigned long long m = __ballot(at_internal);
+            if (m == 0 || (__popcll(m) * 4 <= n_act && __popcll(m) != n_act)) break;
+            if (at_internal) {
+                const float4* rec = S.pairs + (size_t)T.cur * 4;
+                const float4 a = rec[0], b = rec[1], c = rec[2], e = rec[3];
+                float tl, tr;
+                const bool hl = slab(a.x, a.y, a.z, b.x, b.y, b.z, T.o, T.rcp, T.dist, &tl);
+                const bool hr = slab(c.x, c.y, c.z, e.x, e.y, e.z, T.o, T.rcp, T.dist, &tr);
+                if (COUNT) { nn += 2; mine += 2; }
+                const uint32_t lref = __float_as_uint(a.w), rref = __float_as_uint(c.w);
+                if (hl && hr) {
+                    const bool left_first = tl <= tr;  // bvh.rs:211
+                    stk.put(T.sp, left_first ? rref : lref, left_first ? tr : tl);
+                    T.sp += 1;
+                    T.cur = left_first ? lref : rref;
+                } else if (hl) {
+                    T.cur = lref;
+                } else if (hr) {
+                    T.cur = rref;
+                } else if (!lane_pop(T, stk)) {
+                    active = false;
+                }
+            }
+        }
+        // ---- leaf phase
+        if (active && (T.cur & kLeafBit)) {
+            uint32_t first = T.cur & kLeafFirstMask;
+            uint32_t count = (T.cur >> kLeafCountShift) & 31u;
+            if (count == 0) {
+                count = S.big_leaf[2 * first + 1];
+                first = S.big_leaf[2 * first];
+            }
+            if (COUNT) np += count;
+            for (uint32_t k = 0; k < count; ++k) {
+                const uint32_t ps = first + k;
+                if (PRIM == PRIM_TRIANGLE) {
+                    const float4* tp = S.prim + (size_t)ps * 3;
+                    const float4 a = tp[0], b = tp[1], c = tp[2];
+                    float t, u, v, det;
+                    if (tri_hit(V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, V3{b.z, b.w, c.x}, T.o, T.d, &t, &u, &v, &det)) {
+                        T.dist = t;  // unconditionally, triangle.rs:72
+                        T.hslot = ps;
+                        T.hu = u;
+                        T.hv = v;
+                        T.hinside = det < 0.0f ? 1u : 0u;
+                    }
+                } else {
+                    const float4 sp4 = S.prim[ps];
+                    float t;
+                    bool inside;
+                    if (sphere_hit(V3{sp4.x, sp4.y, sp4.z}, sp4.w, T.o, T.d, T.dist, &t, &inside)) {
+                        T.dist = t;
+                        T.hslot = ps;
+                        T.hinside = inside ? 1u : 0u;
+                    }
+                }
+            }
+            if (!lane_pop(T, stk)) active = false;
+        }
+        // ---- lanes whose stack ran empty in this iteration are done: store the hit record (once)
+        const bool just_done = !active && ((act >> lane) & 1ull);
+        if (just_done) {
+            const uint32_t bits = T.hslot == PT_MISS ? PT_MISS : (T.hslot | (T.hinside << 31));
+            P.hit[T.slot] = make_float4(__uint_as_float(bits), T.dist, T.hu, T.hv);
+            if (COUNT) worst = mine > worst ? mine : worst;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(counters + CNT_RAYS_CLOSEST, (unsigned long long)n);
+    if (COUNT) {
+        wave_add(counters + CNT_NODE_TESTS, nn);
+        wave_add(counters + CNT_PRIM_TESTS, np);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t other = __shfl_down(worst, off, 64);
+            worst = other > worst ? other : worst;
+        }
+        if ((threadIdx.x & 63) == 0 && worst) atomicMax(counters + CNT_MAX_NODE_TESTS, (unsigned long long)worst);
+    }
+}
+
 template <int PRIM>
 __device__ __forceinline__ uint32_t prim_material(const DevScene& S, uint32_t slot) {
     return PRIM == PRIM_TRIANGLE ? __float_as_uint(S.prim[(size_t)slot * 3 + 2].z) : S.prim_meta[2 * slot + 1];
@@ -784,9 +970,16 @@ void launch_raygen(const DevCamera* cam, const PixelMap& M, const PathState& P, 
                        nee ? 1 : 0, identity, queue, qn, counters);
 }
 
-void launch_extend(int prim, bool count, const DevScene& S, const PathState& P, const uint32_t* queue, const uint32_t* qn,
-                   const LaunchCfg& cfg, unsigned long long* counters, hipStream_t st) {
+void launch_extend(int prim, bool count, bool simple, const DevScene& S, const PathState& P, const uint32_t* queue, const uint32_t* qn,
+                   uint32_t* cursor, const LaunchCfg& cfg, unsigned long long* counters, hipStream_t st) {
+    if (simple) {
 #define PT_EXT(PR, C) hipLaunchKernelGGL((k_extend<PR, C>), dim3(cfg.grid), dim3(kTraceBlock), 0, st, S, P, queue, qn, cfg, counters)
+        if (prim == PRIM_TRIANGLE) { if (count) PT_EXT(PRIM_TRIANGLE, true); else PT_EXT(PRIM_TRIANGLE, false); }
+        else { if (count) PT_EXT(PRIM_SPHERE, true); else PT_EXT(PRIM_SPHERE, false); }
+#undef PT_EXT
+        return;
+    }
+#define PT_EXT(PR, C) hipLaunchKernelGGL((k_extend_pw<PR, C>), dim3(cfg.grid), dim3(kTraceBlock), 0, st, S, P, queue, qn, cursor, cfg, counters)
     if (prim == PRIM_TRIANGLE) { if (count) PT_EXT(PRIM_TRIANGLE, true); else PT_EXT(PRIM_TRIANGLE, false); }
     else { if (count) PT_EXT(PRIM_SPHERE, true); else PT_EXT(PRIM_SPHERE, false); }
 #undef PT_EXT

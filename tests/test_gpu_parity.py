@@ -348,6 +348,7 @@ def test_scheduling_does_not_change_results(ptcore, pairs, name):
         dict(batch=W * H, lanes=4, tail_min=0, tail_frac=0),          # 6 batches, wavefront rounds only
         dict(batch=2 * W * H, lanes=2, tail_min=1 << 30, tail_frac=1),  # tail kernel takes over after 3 rounds
         dict(batch=W * H, lanes=3, tail_min=64, tail_frac=8),
+        dict(batch=3 * W * H, lanes=2, tail_min=0, tail_frac=0, simple=1),  # one-ray-per-lane traversal kernel
         dict(batch=1 << 23, lanes=1, tail_min=65536, tail_frac=16),    # defaults
     ]
     try:
@@ -356,6 +357,7 @@ def test_scheduling_does_not_change_results(ptcore, pairs, name):
             g.set_option(ptcore.OPT_LANES, cfg["lanes"])
             g.set_option(ptcore.OPT_TAIL_MIN_PATHS, cfg["tail_min"])
             g.set_option(ptcore.OPT_TAIL_FRACTION, cfg["tail_frac"])
+            g.set_option(ptcore.OPT_SIMPLE_EXTEND, cfg.get("simple", 0))
             g.set_camera(cam_o, cam_t, W, H)
             g.reset_counters()
             g.render(spp, 32, seed=21)
@@ -367,4 +369,5 @@ def test_scheduling_does_not_change_results(ptcore, pairs, name):
         g.set_option(ptcore.OPT_BATCH_PATHS, 1 << 23)
         g.set_option(ptcore.OPT_LANES, 8)
         g.set_option(ptcore.OPT_TAIL_MIN_PATHS, 65536)
-        g.set_option(ptcore.OPT_TAIL_FRACTION, 32)
+        g.set_option(ptcore.OPT_TAIL_FRACTION, 16)
+        g.set_option(ptcore.OPT_SIMPLE_EXTEND, 0)
