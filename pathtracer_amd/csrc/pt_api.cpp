@@ -89,14 +89,15 @@ struct pt_ctx {
     size_t spill_bytes = 16;
     DevBuf d_spill;           // spill area of the seams (pt_trace, focus)
     RenderLane lanes[kMaxLanes];
-    hipStream_t tail_stream[4] = {nullptr, nullptr, nullptr, nullptr};  // high priority: the few latency-bound tail waves go first
+    hipStream_t tail_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t bulk_stream[kMaxLanes] = {};  // the round kernels of lane i run on bulk_stream[i % opt_bulk_streams]  // high priority: the few latency-bound tail waves go first
     hipEvent_t last_acc_event = nullptr;
     bool last_acc_valid = false;
     std::vector<hipEvent_t> ext_events, tail_events;
     DevBuf d_counters;
     double extend_ms = 0, render_ms = 0, tail_ms = 0;
     uint64_t extend_launches = 0, tail_launches = 0;
-    uint64_t opt_batch_slots = kTargetSlots, opt_tail_min = kTailMinPaths, opt_tail_fraction = kTailFraction, opt_lanes = kMaxLanes, opt_tail_streams = 4, opt_tail_paths_per_lane = 2, opt_simple_extend = 0;
+    uint64_t opt_batch_slots = kTargetSlots, opt_tail_min = kTailMinPaths, opt_tail_fraction = kTailFraction, opt_lanes = kMaxLanes, opt_tail_streams = 4, opt_tail_paths_per_lane = 4, opt_first_check = 3, opt_simple_extend = 0, opt_bulk_streams = kMaxLanes, opt_tail_mode = 0;
     std::vector<uint32_t> round_sizes;  // queue length of every round of the last finished batch
 
     int fail(int code, const std::string& msg) {
@@ -187,20 +188,20 @@ int pt_create(int device, pt_ctx** out) {
 void pt_destroy(pt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipDeviceSynchronize();
     DevBuf* bufs[] = {&c->d_pairs, &c->d_prim, &c->d_meta, &c->d_nrm, &c->d_big, &c->d_mats, &c->d_sky, &c->d_lights, &c->d_cam,
                       &c->d_accum, &c->d_spill, &c->d_counters};
     for (DevBuf* b : bufs) b->release();
     for (RenderLane& L : c->lanes) {
-        if (L.stream) (void)hipStreamSynchronize(L.stream);
         DevBuf* lb[] = {&L.d_ro, &L.d_rd, &L.d_hit, &L.d_tp, &L.d_out, &L.d_acc, &L.d_pxs, &L.d_q0, &L.d_q1, &L.d_qn, &L.d_spill};
         for (DevBuf* b : lb) b->release();
         if (L.h_qn) (void)hipHostFree(L.h_qn);
         if (L.ev_check) (void)hipEventDestroy(L.ev_check);
         if (L.ev_done) (void)hipEventDestroy(L.ev_done);
-        if (L.stream) (void)hipStreamDestroy(L.stream);
     }
     for (hipStream_t t : c->tail_stream)
+        if (t) { (void)hipStreamSynchronize(t); (void)hipStreamDestroy(t); }
+    for (hipStream_t t : c->bulk_stream)
         if (t) { (void)hipStreamSynchronize(t); (void)hipStreamDestroy(t); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -558,8 +559,7 @@ int pt_sample_skybox(pt_ctx* c, const float* dirs, uint64_t n, float* rgb) {
 // accumulate kernel of batch b waits for the one of batch b-1.
 static int lane_alloc(pt_ctx* c, RenderLane& L, uint64_t slots, uint32_t rounds) {
     int rc;
-    if (!L.stream) {
-        PT_HIP(c, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+    if (!L.ev_check) {
         PT_HIP(c, hipEventCreateWithFlags(&L.ev_check, hipEventDisableTiming));
         PT_HIP(c, hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming));
         PT_HIP(c, hipHostMalloc((void**)&L.h_qn, 64, hipHostMallocDefault));
@@ -646,7 +646,7 @@ static int lane_start(pt_ctx* c, RenderLane& L, const RenderJob& J, uint32_t bat
     if (J.max_depth == 0)  // `for _ in 0..0` never runs: every sample is (0,0,0)
         PT_HIP(c, hipMemsetAsync(L.d_out.p, 0, (size_t)ns * J.M.npix_pad * 16, L.stream));
     // the first rounds carry almost all rays; look at the queue after three of them
-    return lane_issue_rounds(c, L, J, std::min<uint32_t>(3, J.rounds));
+    return lane_issue_rounds(c, L, J, std::min<uint32_t>((uint32_t)c->opt_first_check, J.rounds));
 }
 
 // Hand the batch to its tail stream: (optionally) the fused tail kernel for the paths still alive,
@@ -654,7 +654,33 @@ static int lane_start(pt_ctx* c, RenderLane& L, const RenderJob& J, uint32_t bat
 static int lane_finish(pt_ctx* c, RenderLane& L, const RenderJob& J, uint32_t live) {
     hipStream_t ts = c->tail_stream[L.batch % c->opt_tail_streams];
     PT_HIP(c, hipStreamWaitEvent(ts, L.ev_check, 0));
-    if (live != 0 && L.round < J.rounds) {
+    if (live != 0 && L.round < J.rounds && c->opt_tail_mode == 1) {
+        // tail as further wavefront rounds, all enqueued blindly on the tail stream with a grid sized
+        // for the few paths left (rounds that find an empty queue cost a few microseconds)
+        uint32_t* q[2] = {(uint32_t*)L.d_q0.p, (uint32_t*)L.d_q1.p};
+        uint32_t* qn = (uint32_t*)L.d_qn.p;
+        unsigned long long* counters = (unsigned long long*)c->d_counters.p;
+        LaunchCfg small = L.cfg;
+        small.grid = std::min<uint32_t>(L.cfg.grid, std::max<uint32_t>(16, (live + kTraceBlock - 1) / kTraceBlock));
+        for (uint32_t r = L.round; r < J.rounds; ++r) {
+            if (J.timed) {
+                hipEvent_t a, b;
+                PT_HIP(c, hipEventCreate(&a));
+                PT_HIP(c, hipEventCreate(&b));
+                PT_HIP(c, hipEventRecord(a, ts));
+                launch_extend(c->prim_kind, J.count, c->opt_simple_extend != 0, c->ds, L.ps, q[r & 1], qn + r, qn + J.rounds + 2 + r, small, counters, ts);
+                PT_HIP(c, hipEventRecord(b, ts));
+                c->ext_events.push_back(a);
+                c->ext_events.push_back(b);
+            } else {
+                launch_extend(c->prim_kind, J.count, c->opt_simple_extend != 0, c->ds, L.ps, q[r & 1], qn + r, qn + J.rounds + 2 + r, small, counters, ts);
+            }
+            c->extend_launches += 1;
+            launch_shade(c->prim_kind, c->nee, c->ds, L.ps, J.M, q[r & 1], qn + r, q[(r + 1) & 1], qn + r + 1, J.max_depth, L.sample_base,
+                         J.k0, J.k1, small, counters, ts);
+        }
+        L.round = J.rounds;
+    } else if (live != 0 && L.round < J.rounds) {
         uint32_t* qn = (uint32_t*)L.d_qn.p;
         hipEvent_t a = nullptr, b = nullptr;
         if (J.timed) {
@@ -662,7 +688,7 @@ static int lane_finish(pt_ctx* c, RenderLane& L, const RenderJob& J, uint32_t li
             PT_HIP(c, hipEventCreate(&b));
             PT_HIP(c, hipEventRecord(a, ts));
         }
-        launch_tail(c->prim_kind, c->nee, J.count, c->ds, L.ps, (L.round & 1) ? (uint32_t*)L.d_q1.p : (uint32_t*)L.d_q0.p, qn + L.round,
+        launch_tail(c->prim_kind, c->nee, J.count, (int)c->opt_tail_mode, c->ds, L.ps, (L.round & 1) ? (uint32_t*)L.d_q1.p : (uint32_t*)L.d_q0.p, qn + L.round,
                     qn + 2 * J.rounds + 3, (uint32_t)((live + c->opt_tail_paths_per_lane - 1) / c->opt_tail_paths_per_lane), J.max_depth, J.k0, J.k1, L.cfg, (unsigned long long*)c->d_counters.p, ts);
         if (J.timed) {
             PT_HIP(c, hipEventRecord(b, ts));
@@ -732,6 +758,9 @@ int pt_render(pt_ctx* c, uint32_t spp, uint32_t max_depth, uint64_t seed, const 
     for (uint32_t i = 0; i < n_lanes; ++i) {
         int rc = lane_alloc(c, c->lanes[i], batch_slots, J.rounds);
         if (rc) return rc;
+        hipStream_t& bs = c->bulk_stream[i % c->opt_bulk_streams];
+        if (!bs) PT_HIP(c, hipStreamCreateWithFlags(&bs, hipStreamNonBlocking));
+        c->lanes[i].stream = bs;
         c->lanes[i].state = RenderLane::IDLE;
     }
 
@@ -906,6 +935,9 @@ int pt_set_option(pt_ctx* c, int option, uint64_t value) {
         case PT_OPT_TAIL_MIN_PATHS: c->opt_tail_min = value; return PT_OK;
         case PT_OPT_TAIL_FRACTION: c->opt_tail_fraction = value; return PT_OK;
         case PT_OPT_TAIL_STREAMS: c->opt_tail_streams = std::min<uint64_t>(std::max<uint64_t>(value, 1), 4); return PT_OK;
+        case PT_OPT_BULK_STREAMS: c->opt_bulk_streams = std::min<uint64_t>(std::max<uint64_t>(value, 1), kMaxLanes); return PT_OK;
+        case PT_OPT_FIRST_CHECK_ROUND: c->opt_first_check = std::max<uint64_t>(value, 1); return PT_OK;
+        case PT_OPT_TAIL_MODE: c->opt_tail_mode = value; return PT_OK;
         case PT_OPT_SIMPLE_EXTEND: c->opt_simple_extend = value; return PT_OK;
         case PT_OPT_TAIL_PATHS_PER_LANE: c->opt_tail_paths_per_lane = std::max<uint64_t>(value, 1); return PT_OK;
         default: return c->fail(PT_ERR_INVALID, "pt_set_option: unknown option");

@@ -76,7 +76,7 @@ void launch_extend(int prim, bool count, bool simple, const DevScene& S, const P
 void launch_shade(int prim, bool nee, const DevScene& S, const PathState& P, const PixelMap& M, const uint32_t* q_in, const uint32_t* qn_in,
                   uint32_t* q_out, uint32_t* qn_out, uint32_t depth, uint32_t sample_base, uint32_t k0, uint32_t k1,
                   const LaunchCfg& cfg, unsigned long long* counters, hipStream_t st);
-void launch_tail(int prim, bool nee, bool count, const DevScene& S, const PathState& P, const uint32_t* queue, const uint32_t* qn,
+void launch_tail(int prim, bool nee, bool count, int mode, const DevScene& S, const PathState& P, const uint32_t* queue, const uint32_t* qn,
                  uint32_t* cursor, uint32_t n_hint, uint32_t depth, uint32_t k0, uint32_t k1, const LaunchCfg& cfg, unsigned long long* counters,
                  hipStream_t st);
 void launch_accumulate(const PixelMap& M, const float4* out, uint32_t n_samples, float* accum, hipStream_t st);

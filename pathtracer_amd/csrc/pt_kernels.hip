@@ -41,7 +41,7 @@ struct LaneStack {
     lds_u64* lds;         // &smem[threadIdx.x], kept in the LDS address space so accesses are ds_read/ds_write_b64
     unsigned long long* spill;  // &spill[global thread id]
     uint32_t spill_stride;
-    __device__ __forceinline__ void put(uint32_t level, uint32_t ref, float tmin) {
+    __device__ __forceinline__ void put(uint32_t level, uint32_t ref, float tmin) const {
         const unsigned long long e = (unsigned long long)ref | ((unsigned long long)__float_as_uint(tmin) << 32);
         if (level < (uint32_t)kLdsStack) lds[level * kTraceBlock] = e;
         else spill[(size_t)(level - kLdsStack) * spill_stride] = e;
@@ -456,6 +456,127 @@ __device__ __forceinline__ bool lane_pop(LaneTrav& T, const LaneStack& stk) {
 
 constexpr int kRefillLanes = 20;     // refill when at least this many lanes of the wave are idle
 constexpr int kFetchChunk = 256;     // rays a wave reserves per atomic on the queue cursor
+constexpr int kShadeLanes = 16;      // fused kernel: shade when at least this many lanes wait for it
+
+// load a ray into a lane and do the root test; false = the ray misses the whole scene
+template <bool COUNT>
+__device__ __forceinline__ bool lane_start_ray(const DevScene& S, LaneTrav& T, float4 ro, float4 rd, uint32_t& nn, uint32_t& mine) {
+    T.o = xyz(ro);
+    T.d = xyz(rd);
+    T.rcp = V3{1.0f / T.d.x, 1.0f / T.d.y, 1.0f / T.d.z};
+    T.dist = ro.w;
+    T.hslot = PT_MISS;
+    T.hinside = 0;
+    T.hu = T.hv = 0.f;
+    T.sp = 0;
+    float tmin;
+    if (COUNT) { nn += 1; mine = 1; }
+    if (slab(S.root_min[0], S.root_min[1], S.root_min[2], S.root_max[0], S.root_max[1], S.root_max[2], T.o, T.rcp, T.dist, &tmin)) {
+        T.cur = S.root_ref;
+        return true;
+    }
+    return false;
+}
+
+// internal phase: lanes at internal nodes step until at most a quarter of the traversing lanes still descend
+template <bool COUNT>
+__device__ __forceinline__ void phase_internal(const DevScene& S, LaneTrav& T, bool& active, const LaneStack& stk, int n_act, uint32_t& nn,
+                                               uint32_t& mine) {
+    while (true) {
+        const bool at_internal = active && !(T.cur & kLeafBit);
+        const unsigned long long m = __ballot(at_internal);
+        if (m == 0 || (__popcll(m) * 4 <= n_act && __popcll(m) != n_act)) break;
+        if (at_internal) {
+            const float4* rec = S.pairs + (size_t)T.cur * 4;
+            const float4 a = rec[0], b = rec[1], c = rec[2], e = rec[3];
+            float tl, tr;
+            const bool hl = slab(a.x, a.y, a.z, b.x, b.y, b.z, T.o, T.rcp, T.dist, &tl);
+            const bool hr = slab(c.x, c.y, c.z, e.x, e.y, e.z, T.o, T.rcp, T.dist, &tr);
+            if (COUNT) { nn += 2; mine += 2; }
+            const uint32_t lref = __float_as_uint(a.w), rref = __float_as_uint(c.w);
+            if (hl && hr) {
+                const bool left_first = tl <= tr;  // bvh.rs:211
+                stk.put(T.sp, left_first ? rref : lref, left_first ? tr : tl);
+                T.sp += 1;
+                T.cur = left_first ? lref : rref;
+            } else if (hl) {
+                T.cur = lref;
+            } else if (hr) {
+                T.cur = rref;
+            } else if (!lane_pop(T, stk)) {
+                active = false;
+            }
+        }
+    }
+}
+
+// leaf phase: lanes at a leaf test its primitives in index order (last accepted wins), then pop
+template <int PRIM, bool COUNT>
+__device__ __forceinline__ void phase_leaf(const DevScene& S, LaneTrav& T, bool& active, const LaneStack& stk, uint32_t& np) {
+    if (active && (T.cur & kLeafBit)) {
+        uint32_t first = T.cur & kLeafFirstMask;
+        uint32_t count = (T.cur >> kLeafCountShift) & 31u;
+        if (count == 0) {
+            count = S.big_leaf[2 * first + 1];
+            first = S.big_leaf[2 * first];
+        }
+        if (COUNT) np += count;
+        for (uint32_t k = 0; k < count; ++k) {
+            const uint32_t ps = first + k;
+            if (PRIM == PRIM_TRIANGLE) {
+                const float4* tp = S.prim + (size_t)ps * 3;
+                const float4 a = tp[0], b = tp[1], c = tp[2];
+                float t, u, v, det;
+                if (tri_hit(V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, V3{b.z, b.w, c.x}, T.o, T.d, &t, &u, &v, &det)) {
+                    T.dist = t;  // unconditionally, triangle.rs:72
+                    T.hslot = ps;
+                    T.hu = u;
+                    T.hv = v;
+                    T.hinside = det < 0.0f ? 1u : 0u;
+                }
+            } else {
+                const float4 sp4 = S.prim[ps];
+                float t;
+                bool inside;
+                if (sphere_hit(V3{sp4.x, sp4.y, sp4.z}, sp4.w, T.o, T.d, T.dist, &t, &inside)) {
+                    T.dist = t;
+                    T.hslot = ps;
+                    T.hinside = inside ? 1u : 0u;
+                }
+            }
+        }
+        if (!lane_pop(T, stk)) active = false;
+    }
+}
+
+__device__ __forceinline__ void lane_store_hit(const PathState& P, const LaneTrav& T) {
+    const uint32_t bits = T.hslot == PT_MISS ? PT_MISS : (T.hslot | (T.hinside << 31));
+    P.hit[T.slot] = make_float4(__uint_as_float(bits), T.dist, T.hu, T.hv);
+}
+
+// wave-uniform: make sure this wave owns a piece of the queue; returns false once the queue is used up
+__device__ __forceinline__ bool wave_fetch_chunk(uint32_t* cursor, uint32_t n, uint32_t chunk, uint32_t& chunk_next, uint32_t& chunk_end) {
+    if (chunk_next < chunk_end) return true;
+    uint32_t base = 0;
+    if ((threadIdx.x & 63u) == 0) base = atomicAdd(cursor, chunk);
+    base = __builtin_amdgcn_readfirstlane(__shfl(base, 0, 64));
+    if (base >= n) {
+        chunk_next = chunk_end = 0;
+        return false;
+    }
+    chunk_next = base;
+    chunk_end = base + chunk < n ? base + chunk : n;
+    return true;
+}
+
+__device__ __forceinline__ void reduce_worst(unsigned long long* counters, uint32_t worst) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t other = __shfl_down(worst, off, 64);
+        worst = other > worst ? other : worst;
+    }
+    if ((threadIdx.x & 63) == 0 && worst) atomicMax(counters + CNT_MAX_NODE_TESTS, (unsigned long long)worst);
+}
 
 template <int PRIM, bool COUNT>
 __global__ __launch_bounds__(kTraceBlock) void k_extend_pw(DevScene S, PathState P, const uint32_t* __restrict__ queue,
@@ -479,39 +600,14 @@ __global__ __launch_bounds__(kTraceBlock) void k_extend_pw(DevScene S, PathState
     while (true) {
         const unsigned long long idle = __ballot(!active);
         const int n_idle = __popcll(idle);
-        if (!drained && (n_idle >= kRefillLanes)) {
-            if (chunk_next >= chunk_end) {  // wave-uniform: take the next kFetchChunk rays of the queue (one atomic)
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(cursor, chunk);
-                base = __builtin_amdgcn_readfirstlane(__shfl(base, 0, 64));
-                chunk_next = base;
-                chunk_end = base + chunk < n ? base + chunk : n;
-                if (base >= n) {
-                    drained = true;
-                    chunk_next = chunk_end = 0;
-                }
-            }
+        if (!drained && n_idle >= kRefillLanes) {
+            if (!wave_fetch_chunk(cursor, n, chunk, chunk_next, chunk_end)) drained = true;
             if (!active && !drained) {
                 const uint32_t idx = chunk_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                 if (idx < chunk_end) {
                     T.slot = queue[idx];
-                    const float4 ro = P.ro[T.slot], rd = P.rd[T.slot];
-                    T.o = xyz(ro);
-                    T.d = xyz(rd);
-                    T.rcp = V3{1.0f / T.d.x, 1.0f / T.d.y, 1.0f / T.d.z};
-                    T.dist = ro.w;
-                    T.hslot = PT_MISS;
-                    T.hinside = 0;
-                    T.hu = T.hv = 0.f;
-                    T.sp = 0;
-                    float tmin;
-                    if (COUNT) { nn += 1; mine = 1; }
-                    if (slab(S.root_min[0], S.root_min[1], S.root_min[2], S.root_max[0], S.root_max[1], S.root_max[2], T.o, T.rcp, T.dist, &tmin)) {
-                        T.cur = S.root_ref;
-                        active = true;
-                    } else {
-                        P.hit[T.slot] = make_float4(__uint_as_float(PT_MISS), T.dist, 0.f, 0.f);
-                    }
+                    active = lane_start_ray<COUNT>(S, T, P.ro[T.slot], P.rd[T.slot], nn, mine);
+                    if (!active) lane_store_hit(P, T);  // misses the root box: done at once
                 }
             }
             chunk_next = chunk_next + (uint32_t)n_idle < chunk_end ? chunk_next + (uint32_t)n_idle : chunk_end;
@@ -521,74 +617,11 @@ __global__ __launch_bounds__(kTraceBlock) void k_extend_pw(DevScene S, PathState
             if (drained) break;
             continue;
         }
-        // ---- internal phase
-        const int n_act = __popcll(act);
-        while (true) {
-            const bool at_internal = active && !(T.cur & kLeafBit);
-            const unsigned long long m = __ballot(at_internal);
-            if (m == 0 || (__popcll(m) * 4 <= n_act && __popcll(m) != n_act)) break;
-            if (at_internal) {
-                const float4* rec = S.pairs + (size_t)T.cur * 4;
-                const float4 a = rec[0], b = rec[1], c = rec[2], e = rec[3];
-                float tl, tr;
-                const bool hl = slab(a.x, a.y, a.z, b.x, b.y, b.z, T.o, T.rcp, T.dist, &tl);
-                const bool hr = slab(c.x, c.y, c.z, e.x, e.y, e.z, T.o, T.rcp, T.dist, &tr);
-                if (COUNT) { nn += 2; mine += 2; }
-                const uint32_t lref = __float_as_uint(a.w), rref = __float_as_uint(c.w);
-                if (hl && hr) {
-                    const bool left_first = tl <= tr;  // bvh.rs:211
-                    stk.put(T.sp, left_first ? rref : lref, left_first ? tr : tl);
-                    T.sp += 1;
-                    T.cur = left_first ? lref : rref;
-                } else if (hl) {
-                    T.cur = lref;
-                } else if (hr) {
-                    T.cur = rref;
-                } else if (!lane_pop(T, stk)) {
-                    active = false;
-                }
-            }
-        }
-        // ---- leaf phase
-        if (active && (T.cur & kLeafBit)) {
-            uint32_t first = T.cur & kLeafFirstMask;
-            uint32_t count = (T.cur >> kLeafCountShift) & 31u;
-            if (count == 0) {
-                count = S.big_leaf[2 * first + 1];
-                first = S.big_leaf[2 * first];
-            }
-            if (COUNT) np += count;
-            for (uint32_t k = 0; k < count; ++k) {
-                const uint32_t ps = first + k;
-                if (PRIM == PRIM_TRIANGLE) {
-                    const float4* tp = S.prim + (size_t)ps * 3;
-                    const float4 a = tp[0], b = tp[1], c = tp[2];
-                    float t, u, v, det;
-                    if (tri_hit(V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, V3{b.z, b.w, c.x}, T.o, T.d, &t, &u, &v, &det)) {
-                        T.dist = t;  // unconditionally, triangle.rs:72
-                        T.hslot = ps;
-                        T.hu = u;
-                        T.hv = v;
-                        T.hinside = det < 0.0f ? 1u : 0u;
-                    }
-                } else {
-                    const float4 sp4 = S.prim[ps];
-                    float t;
-                    bool inside;
-                    if (sphere_hit(V3{sp4.x, sp4.y, sp4.z}, sp4.w, T.o, T.d, T.dist, &t, &inside)) {
-                        T.dist = t;
-                        T.hslot = ps;
-                        T.hinside = inside ? 1u : 0u;
-                    }
-                }
-            }
-            if (!lane_pop(T, stk)) active = false;
-        }
-        // ---- lanes whose stack ran empty in this iteration are done: store the hit record (once)
-        const bool just_done = !active && ((act >> lane) & 1ull);
-        if (just_done) {
-            const uint32_t bits = T.hslot == PT_MISS ? PT_MISS : (T.hslot | (T.hinside << 31));
-            P.hit[T.slot] = make_float4(__uint_as_float(bits), T.dist, T.hu, T.hv);
+        phase_internal<COUNT>(S, T, active, stk, __popcll(act), nn, mine);
+        phase_leaf<PRIM, COUNT>(S, T, active, stk, np);
+        // lanes whose stack ran empty in this iteration are done: store the hit record (once)
+        if (!active && ((act >> lane) & 1ull)) {
+            lane_store_hit(P, T);
             if (COUNT) worst = mine > worst ? mine : worst;
         }
     }
@@ -596,12 +629,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_extend_pw(DevScene S, PathState
     if (COUNT) {
         wave_add(counters + CNT_NODE_TESTS, nn);
         wave_add(counters + CNT_PRIM_TESTS, np);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const uint32_t other = __shfl_down(worst, off, 64);
-            worst = other > worst ? other : worst;
-        }
-        if ((threadIdx.x & 63) == 0 && worst) atomicMax(counters + CNT_MAX_NODE_TESTS, (unsigned long long)worst);
+        reduce_worst(counters, worst);
     }
 }
 
@@ -898,6 +926,86 @@ __global__ __launch_bounds__(kTraceBlock) void k_tail(DevScene S, PathState P, c
     }
 }
 
+// k_tail_pw — the tail as ONE persistent kernel with phase scheduling.  Every lane is idle, traversing
+// or waiting to be shaded.  The wave runs the shared internal / leaf phases of k_extend_pw for the
+// traversing lanes; when kShadeLanes lanes wait for shading (or nobody is traversing any more) it
+// shades them together and puts the survivors' next rays straight back into traversal; idle lanes
+// take fresh paths from the queue.  Same shade_one / phase functions as the round kernels.
+template <int PRIM, bool NEE, bool COUNT>
+__global__ __launch_bounds__(kTraceBlock) void k_tail_pw(DevScene S, PathState P, const uint32_t* __restrict__ queue,
+                                                         const uint32_t* __restrict__ qn, uint32_t* __restrict__ cursor, uint32_t depth,
+                                                         uint32_t k0, uint32_t k1, LaunchCfg cfg, unsigned long long* counters) {
+    __shared__ unsigned long long smem[kLdsStack * kTraceBlock];
+    LaneStack stk = make_stack(smem, cfg);
+    const uint32_t n = *qn;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t nn = 0, np = 0, worst = 0, mine = 0, rays = 0;
+    LaneTrav T;
+    T.cur = 0; T.sp = 0; T.dist = 0.f; T.hslot = PT_MISS; T.hinside = 0; T.hu = T.hv = 0.f; T.slot = 0;
+    T.o = T.d = T.rcp = V3{0.f, 0.f, 0.f};
+    bool active = false;   // traversing
+    bool pending = false;  // traversal finished, hit record stored, waits for shade_one
+    bool drained = false;
+    uint32_t chunk_next = 0, chunk_end = 0;
+    const uint32_t chunk = 32;
+    while (true) {
+        unsigned long long pend = __ballot(pending);
+        unsigned long long act = __ballot(active);
+        if (pend != 0 && (__popcll(pend) >= kShadeLanes || act == 0)) {
+            if (pending) {
+                pending = false;
+                if (shade_one<PRIM, NEE>(S, P, T.slot, depth, k0, k1, stk, counters)) {
+                    rays += 1;
+                    active = lane_start_ray<COUNT>(S, T, P.ro[T.slot], P.rd[T.slot], nn, mine);
+                    if (!active) {
+                        lane_store_hit(P, T);
+                        pending = true;
+                    }
+                }
+            }
+            continue;
+        }
+        const unsigned long long idle = __ballot(!active && !pending);
+        const int n_idle = __popcll(idle);
+        if (!drained && n_idle >= kRefillLanes) {
+            if (!wave_fetch_chunk(cursor, n, chunk, chunk_next, chunk_end)) drained = true;
+            if (!active && !pending && !drained) {
+                const uint32_t idx = chunk_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                if (idx < chunk_end) {
+                    T.slot = queue[idx];
+                    rays += 1;
+                    active = lane_start_ray<COUNT>(S, T, P.ro[T.slot], P.rd[T.slot], nn, mine);
+                    if (!active) {
+                        lane_store_hit(P, T);
+                        pending = true;
+                    }
+                }
+            }
+            chunk_next = chunk_next + (uint32_t)n_idle < chunk_end ? chunk_next + (uint32_t)n_idle : chunk_end;
+            continue;
+        }
+        if (act == 0) {
+            if (pend != 0) continue;  // (cannot happen: pend != 0 with act == 0 is shaded above)
+            if (drained) break;
+            continue;  // fewer than kRefillLanes idle cannot be: everyone is idle here
+        }
+        phase_internal<COUNT>(S, T, active, stk, __popcll(act), nn, mine);
+        phase_leaf<PRIM, COUNT>(S, T, active, stk, np);
+        if (!active && ((act >> lane) & 1ull)) {
+            lane_store_hit(P, T);
+            pending = true;
+            if (COUNT) worst = mine > worst ? mine : worst;
+        }
+    }
+    wave_add(counters + CNT_RAYS_CLOSEST, rays);
+    wave_add(counters + CNT_TAIL_RAYS, rays);
+    if (COUNT) {
+        wave_add(counters + CNT_TAIL_NODE_TESTS, nn);
+        wave_add(counters + CNT_TAIL_PRIM_TESTS, np);
+        reduce_worst(counters, worst);
+    }
+}
+
 // chunk[idx] += sample, src/main.rs:159 — samples of one pixel are added in sample order, so the
 // sum is the one the reference's frame loop builds one frame at a time.
 __global__ __launch_bounds__(256) void k_accumulate(PixelMap M, const float4* __restrict__ out, uint32_t n_samples, float* __restrict__ accum) {
@@ -996,19 +1104,22 @@ void launch_shade(int prim, bool nee, const DevScene& S, const PathState& P, con
 #undef PT_SH
 }
 
-void launch_tail(int prim, bool nee, bool count, const DevScene& S, const PathState& P, const uint32_t* queue, const uint32_t* qn,
+void launch_tail(int prim, bool nee, bool count, int mode, const DevScene& S, const PathState& P, const uint32_t* queue, const uint32_t* qn,
                  uint32_t* cursor, uint32_t n_hint, uint32_t depth, uint32_t k0, uint32_t k1, const LaunchCfg& cfg,
                  unsigned long long* counters, hipStream_t st) {
-    // persistent: about a quarter of the paths get a lane at once, the rest are fetched as lanes free up
-    const uint32_t grid = blocks_for(n_hint, kTraceBlock, cfg.grid);  // n_hint lanes; further paths are fetched as lanes free up
-#define PT_TAIL(PR, N, C) hipLaunchKernelGGL((k_tail<PR, N, C>), dim3(grid), dim3(kTraceBlock), 0, st, S, P, queue, qn, cursor, depth, k0, k1, cfg, counters)
-    if (prim == PRIM_TRIANGLE) {
-        if (nee) { if (count) PT_TAIL(PRIM_TRIANGLE, true, true); else PT_TAIL(PRIM_TRIANGLE, true, false); }
-        else { if (count) PT_TAIL(PRIM_TRIANGLE, false, true); else PT_TAIL(PRIM_TRIANGLE, false, false); }
-    } else {
-        if (nee) { if (count) PT_TAIL(PRIM_SPHERE, true, true); else PT_TAIL(PRIM_SPHERE, true, false); }
-        else { if (count) PT_TAIL(PRIM_SPHERE, false, true); else PT_TAIL(PRIM_SPHERE, false, false); }
+    // n_hint lanes; further paths are fetched as lanes free up
+    const uint32_t grid = blocks_for(n_hint, kTraceBlock, cfg.grid);
+#define PT_TAIL(K, PR, N, C) hipLaunchKernelGGL((K<PR, N, C>), dim3(grid), dim3(kTraceBlock), 0, st, S, P, queue, qn, cursor, depth, k0, k1, cfg, counters)
+#define PT_TAIL_ALL(K)                                                                                                  \
+    if (prim == PRIM_TRIANGLE) {                                                                                        \
+        if (nee) { if (count) PT_TAIL(K, PRIM_TRIANGLE, true, true); else PT_TAIL(K, PRIM_TRIANGLE, true, false); }     \
+        else { if (count) PT_TAIL(K, PRIM_TRIANGLE, false, true); else PT_TAIL(K, PRIM_TRIANGLE, false, false); }       \
+    } else {                                                                                                            \
+        if (nee) { if (count) PT_TAIL(K, PRIM_SPHERE, true, true); else PT_TAIL(K, PRIM_SPHERE, true, false); }         \
+        else { if (count) PT_TAIL(K, PRIM_SPHERE, false, true); else PT_TAIL(K, PRIM_SPHERE, false, false); }           \
     }
+    if (mode == 2) { PT_TAIL_ALL(k_tail) } else { PT_TAIL_ALL(k_tail_pw) }
+#undef PT_TAIL_ALL
 #undef PT_TAIL
 }
 
