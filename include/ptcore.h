@@ -192,12 +192,13 @@ int pt_sample_skybox(pt_ctx *ctx, const float *dirs, uint64_t n, float *rgb);
  *  PT_OPT_TAIL_STREAMS    streams the tail kernels are spread over, 1..4 (default 4)
  *  PT_OPT_TAIL_PATHS_PER_LANE  paths each tail-kernel lane works through on average (default 4)
  *  PT_OPT_BULK_STREAMS    streams the round kernels of the lanes are spread over, 1..8 (default 8)
+ *  PT_OPT_RENDER_MODE     0 = wavefront rounds + tail kernel, 1 = one persistent kernel per batch (k_path)
  *  PT_OPT_FIRST_CHECK_ROUND  rounds enqueued before the live-path count is first looked at (default 3)
  *  PT_OPT_TAIL_MODE       0 = fused phase-scheduled tail kernel, 1 = further rounds on the tail stream with a small
  *                         grid, 2 = fused tail kernel that traces and shades in lock step
  *  PT_OPT_SIMPLE_EXTEND   1 = one-ray-per-lane traversal kernel instead of the persistent one (A/B, tests) */
 enum { PT_OPT_BATCH_PATHS = 0, PT_OPT_LANES = 1, PT_OPT_TAIL_MIN_PATHS = 2, PT_OPT_TAIL_FRACTION = 3,
-       PT_OPT_TAIL_STREAMS = 4, PT_OPT_TAIL_PATHS_PER_LANE = 5, PT_OPT_SIMPLE_EXTEND = 6, PT_OPT_BULK_STREAMS = 7, PT_OPT_TAIL_MODE = 8, PT_OPT_FIRST_CHECK_ROUND = 9 };
+       PT_OPT_TAIL_STREAMS = 4, PT_OPT_TAIL_PATHS_PER_LANE = 5, PT_OPT_SIMPLE_EXTEND = 6, PT_OPT_BULK_STREAMS = 7, PT_OPT_TAIL_MODE = 8, PT_OPT_FIRST_CHECK_ROUND = 9, PT_OPT_RENDER_MODE = 10 };
 int pt_set_option(pt_ctx *ctx, int option, uint64_t value);
 int pt_get_counters(pt_ctx *ctx, pt_counters *out);
 /* Diagnostics of the wavefront loop (no counterpart in the reference): after a pt_render with

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -40,7 +41,7 @@ constexpr uint64_t kTailFraction = 16;         // ... or below 1/16 of the batch
 
 // One batch in flight.
 struct RenderLane {
-    enum State { IDLE, RUNNING, READY, DRAINING };
+    enum State { IDLE, RUNNING, TAILING, READY, DRAINING };
     State state = IDLE;
     hipStream_t stream = nullptr;
     hipEvent_t ev_check = nullptr, ev_done = nullptr;
@@ -97,7 +98,7 @@ struct pt_ctx {
     DevBuf d_counters;
     double extend_ms = 0, render_ms = 0, tail_ms = 0;
     uint64_t extend_launches = 0, tail_launches = 0;
-    uint64_t opt_batch_slots = kTargetSlots, opt_tail_min = kTailMinPaths, opt_tail_fraction = kTailFraction, opt_lanes = kMaxLanes, opt_tail_streams = 4, opt_tail_paths_per_lane = 4, opt_first_check = 3, opt_simple_extend = 0, opt_bulk_streams = kMaxLanes, opt_tail_mode = 0;
+    uint64_t opt_batch_slots = kTargetSlots, opt_tail_min = kTailMinPaths, opt_tail_fraction = kTailFraction, opt_lanes = kMaxLanes, opt_tail_streams = 4, opt_tail_paths_per_lane = 4, opt_first_check = 3, opt_simple_extend = 0, opt_bulk_streams = kMaxLanes, opt_tail_mode = 0, opt_render_mode = 0;
     std::vector<uint32_t> round_sizes;  // queue length of every round of the last finished batch
 
     int fail(int code, const std::string& msg) {
@@ -564,7 +565,9 @@ static int lane_alloc(pt_ctx* c, RenderLane& L, uint64_t slots, uint32_t rounds)
         PT_HIP(c, hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming));
         PT_HIP(c, hipHostMalloc((void**)&L.h_qn, 64, hipHostMallocDefault));
     }
-    if (slots > L.cap_slots) {
+    if (c->opt_render_mode == 1) {  // k_path keeps the path state in registers: only the radiance slab is needed
+        if ((rc = dev_alloc(c, L.d_out, slots * 16))) return rc;
+    } else if (slots > L.cap_slots) {
         if ((rc = dev_alloc(c, L.d_ro, slots * 16))) return rc;
         if ((rc = dev_alloc(c, L.d_rd, slots * 16))) return rc;
         if ((rc = dev_alloc(c, L.d_hit, slots * 16))) return rc;
@@ -575,7 +578,7 @@ static int lane_alloc(pt_ctx* c, RenderLane& L, uint64_t slots, uint32_t rounds)
         if ((rc = dev_alloc(c, L.d_q1, slots * 4))) return rc;
         L.cap_slots = slots;
     }
-    if (c->nee && L.d_acc.bytes < slots * 16)
+    if (c->opt_render_mode != 1 && c->nee && L.d_acc.bytes < slots * 16)
         if ((rc = dev_alloc(c, L.d_acc, slots * 16))) return rc;
     if (rounds + 2 > L.qn_len) {  // queue lengths [0, rounds+2) then one fetch cursor per round
         if ((rc = dev_alloc(c, L.d_qn, (size_t)(rounds + 2) * 8))) return rc;
@@ -641,6 +644,29 @@ static int lane_start(pt_ctx* c, RenderLane& L, const RenderJob& J, uint32_t bat
     L.round = 0;
     L.state = RenderLane::RUNNING;
     PT_HIP(c, hipMemsetAsync(qn, 0, (size_t)(J.rounds + 2) * 8, L.stream));
+    if (c->opt_render_mode == 1) {
+        // the whole batch in one persistent kernel (generate + sample, state in registers)
+        hipEvent_t a = nullptr, b = nullptr;
+        if (J.timed) {
+            PT_HIP(c, hipEventCreate(&a));
+            PT_HIP(c, hipEventCreate(&b));
+            PT_HIP(c, hipEventRecord(a, L.stream));
+        }
+        launch_path(c->prim_kind, c->nee, J.count, c->ds, (const DevCamera*)c->d_cam.p, J.M, ns, sample_base, J.max_depth, J.k0, J.k1,
+                    L.ps.out, qn, L.cfg, (unsigned long long*)c->d_counters.p, L.stream);
+        if (J.timed) {
+            PT_HIP(c, hipEventRecord(b, L.stream));
+            c->tail_events.push_back(a);
+            c->tail_events.push_back(b);
+        }
+        c->tail_launches += 1;
+        PT_HIP(c, hipEventRecord(L.ev_check, L.stream));
+        PT_HIP(c, hipGetLastError());
+        L.round = J.rounds;
+        L.live = 0;
+        L.state = RenderLane::TAILING;  // ev_check now stands for the whole batch
+        return PT_OK;
+    }
     launch_raygen((const DevCamera*)c->d_cam.p, J.M, L.ps, ns, sample_base, J.k0, J.k1, c->nee, (uint32_t*)L.d_q0.p, qn,
                   (unsigned long long*)c->d_counters.p, L.stream);
     if (J.max_depth == 0)  // `for _ in 0..0` never runs: every sample is (0,0,0)
@@ -649,11 +675,13 @@ static int lane_start(pt_ctx* c, RenderLane& L, const RenderJob& J, uint32_t bat
     return lane_issue_rounds(c, L, J, std::min<uint32_t>((uint32_t)c->opt_first_check, J.rounds));
 }
 
-// Hand the batch to its tail stream: (optionally) the fused tail kernel for the paths still alive,
-// then the accumulation of the batch's samples, in batch order.
-static int lane_finish(pt_ctx* c, RenderLane& L, const RenderJob& J, uint32_t live) {
+// No stream ever waits on an event of another stream that is still pending: streams share hardware
+// queues, and a barrier packet waiting for work queued behind another such barrier would deadlock.
+// The host therefore polls (ev_check / ev_done) and only then enqueues the dependent work.
+
+// The paths still alive after the rounds go to the batch's tail stream (ev_check has completed).
+static int lane_tail(pt_ctx* c, RenderLane& L, const RenderJob& J, uint32_t live) {
     hipStream_t ts = c->tail_stream[L.batch % c->opt_tail_streams];
-    PT_HIP(c, hipStreamWaitEvent(ts, L.ev_check, 0));
     if (live != 0 && L.round < J.rounds && c->opt_tail_mode == 1) {
         // tail as further wavefront rounds, all enqueued blindly on the tail stream with a grid sized
         // for the few paths left (rounds that find an empty queue cost a few microseconds)
@@ -697,7 +725,15 @@ static int lane_finish(pt_ctx* c, RenderLane& L, const RenderJob& J, uint32_t li
         }
         c->tail_launches += 1;
     }
-    if (c->last_acc_valid) PT_HIP(c, hipStreamWaitEvent(ts, c->last_acc_event, 0));
+    PT_HIP(c, hipEventRecord(L.ev_check, ts));
+    PT_HIP(c, hipGetLastError());
+    L.state = RenderLane::TAILING;
+    return PT_OK;
+}
+
+// All paths of the batch are finished and the previous batch has been added: add this batch's samples.
+static int lane_accumulate(pt_ctx* c, RenderLane& L, const RenderJob& J) {
+    hipStream_t ts = c->tail_stream[L.batch % c->opt_tail_streams];
     launch_accumulate(J.M, L.ps.out, L.ns, (float*)c->d_accum.p, ts);
     PT_HIP(c, hipEventRecord(L.ev_done, ts));
     PT_HIP(c, hipGetLastError());
@@ -775,6 +811,8 @@ int pt_render(pt_ctx* c, uint32_t spp, uint32_t max_depth, uint64_t seed, const 
     c->tail_events.clear();
 
     uint32_t next_batch = 0, finished = 0, next_acc = 0;
+    const bool dbg = std::getenv("PTCORE_DEBUG") != nullptr;
+    uint64_t spins = 0;
     while (finished < n_batches) {
         bool progressed = false;
         for (uint32_t i = 0; i < n_lanes; ++i) {
@@ -793,17 +831,29 @@ int pt_render(pt_ctx* c, uint32_t spp, uint32_t max_depth, uint64_t seed, const 
                 progressed = true;
                 const uint32_t live = *L.h_qn;
                 int rc = PT_OK;
-                if (live == 0 || L.round >= J.rounds || live <= J.tail_threshold) {
-                    L.live = live;
+                if (live == 0 || L.round >= J.rounds) {
                     L.state = RenderLane::READY;
+                } else if (live <= J.tail_threshold) {
+                    rc = lane_tail(c, L, J, live);
                 } else {
                     rc = lane_issue_rounds(c, L, J, std::min<uint32_t>(L.round + 2, J.rounds));
                 }
                 if (rc) return rc;
+            } else if (L.state == RenderLane::TAILING) {
+                hipError_t q = hipEventQuery(L.ev_check);
+                if (q == hipErrorNotReady) continue;
+                if (q != hipSuccess) return c->fail(PT_ERR_HIP, std::string("pt_render: ") + hipGetErrorString(q));
+                L.state = RenderLane::READY;
+                progressed = true;
             }
             if (L.state == RenderLane::READY && L.batch == next_acc) {
-                // batches are handed over in order so every pixel's sum is built in sample order
-                int rc = lane_finish(c, L, J, L.live);
+                // batches are added in order so every pixel's sum is built in sample order
+                if (c->last_acc_valid) {
+                    hipError_t q = hipEventQuery(c->last_acc_event);
+                    if (q == hipErrorNotReady) continue;
+                    if (q != hipSuccess) return c->fail(PT_ERR_HIP, std::string("pt_render: ") + hipGetErrorString(q));
+                }
+                int rc = lane_accumulate(c, L, J);
                 if (rc) return rc;
                 next_acc += 1;
                 progressed = true;
@@ -820,7 +870,14 @@ int pt_render(pt_ctx* c, uint32_t spp, uint32_t max_depth, uint64_t seed, const 
                 progressed = true;
             }
         }
-        if (!progressed) std::this_thread::yield();  // poll: any lane may be the next one to need the host
+        if (!progressed) {
+            std::this_thread::yield();
+            if (dbg && (++spins % 2000000) == 0) {
+                std::fprintf(stderr, "[ptcore] waiting: next_batch %u finished %u next_acc %u states", next_batch, finished, next_acc);
+                for (uint32_t i = 0; i < n_lanes; ++i) std::fprintf(stderr, " %d(b%u)", (int)c->lanes[i].state, c->lanes[i].batch);
+                std::fprintf(stderr, "\n");
+            }
+        }  // poll: any lane may be the next one to need the host
     }
     if (c->last_acc_valid) PT_HIP(c, hipStreamWaitEvent(c->stream, c->last_acc_event, 0));
     PT_HIP(c, hipEventRecord(ev_end, c->stream));
@@ -936,7 +993,8 @@ int pt_set_option(pt_ctx* c, int option, uint64_t value) {
         case PT_OPT_TAIL_FRACTION: c->opt_tail_fraction = value; return PT_OK;
         case PT_OPT_TAIL_STREAMS: c->opt_tail_streams = std::min<uint64_t>(std::max<uint64_t>(value, 1), 4); return PT_OK;
         case PT_OPT_BULK_STREAMS: c->opt_bulk_streams = std::min<uint64_t>(std::max<uint64_t>(value, 1), kMaxLanes); return PT_OK;
-        case PT_OPT_FIRST_CHECK_ROUND: c->opt_first_check = std::max<uint64_t>(value, 1); return PT_OK;
+        case PT_OPT_FIRST_CHECK_ROUND: c->opt_first_check = value; return PT_OK;
+        case PT_OPT_RENDER_MODE: c->opt_render_mode = value; return PT_OK;
         case PT_OPT_TAIL_MODE: c->opt_tail_mode = value; return PT_OK;
         case PT_OPT_SIMPLE_EXTEND: c->opt_simple_extend = value; return PT_OK;
         case PT_OPT_TAIL_PATHS_PER_LANE: c->opt_tail_paths_per_lane = std::max<uint64_t>(value, 1); return PT_OK;

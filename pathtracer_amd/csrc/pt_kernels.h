@@ -79,6 +79,9 @@ void launch_shade(int prim, bool nee, const DevScene& S, const PathState& P, con
 void launch_tail(int prim, bool nee, bool count, int mode, const DevScene& S, const PathState& P, const uint32_t* queue, const uint32_t* qn,
                  uint32_t* cursor, uint32_t n_hint, uint32_t depth, uint32_t k0, uint32_t k1, const LaunchCfg& cfg, unsigned long long* counters,
                  hipStream_t st);
+void launch_path(int prim, bool nee, bool count, const DevScene& S, const DevCamera* cam, const PixelMap& M, uint32_t n_samples,
+                 uint32_t sample_base, uint32_t depth, uint32_t k0, uint32_t k1, float4* out, uint32_t* cursor, const LaunchCfg& cfg,
+                 unsigned long long* counters, hipStream_t st);
 void launch_accumulate(const PixelMap& M, const float4* out, uint32_t n_samples, float* accum, hipStream_t st);
 void launch_resolve(const float* accum, uint32_t width, uint32_t height, float scale, uint8_t* rgb, uint64_t pitch, hipStream_t st);
 

@@ -638,36 +638,49 @@ __device__ __forceinline__ uint32_t prim_material(const DevScene& S, uint32_t sl
     return PRIM == PRIM_TRIANGLE ? __float_as_uint(S.prim[(size_t)slot * 3 + 2].z) : S.prim_meta[2 * slot + 1];
 }
 
-__device__ __forceinline__ void finish(const PathState& P, uint32_t slot, V3 radiance) {
-    P.out[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
-}
+// The state of one path between two traces — what Camera::sample keeps in locals
+// (src/camera.rs:296-298) plus the ray, whether it lives in registers (k_path) or in HBM (k_shade).
+struct PathVals {
+    V3 o, d;          // the ray that was traced / the next ray to trace
+    float tmax;       // ray.distance to start the next trace with
+    float cos_i;      // cos_intersection saved across the look-ahead trace (camera.rs:358)
+    V3 transport;
+    uint32_t flags;   // iteration | phase << 16 | material << 17
+    V3 acc;           // accumalated_color (only non-zero with NEE)
+    uint32_t pixel, sample;  // RNG counter words
+};
+struct HitVals {
+    uint32_t bits;    // slot | inside << 31, or PT_MISS
+    float t, u, v;    // ray.distance after the trace, barycentrics
+};
 
 // One step of the loop body of Camera::sample (src/camera.rs:299-421) for one path.
-// Returns true when the path stays alive (its next ray is in P.ro / P.rd).
+// Returns true when the path stays alive (pv then holds its next ray); false when it ended
+// (radiance then holds what Camera::sample returns).
 template <int PRIM, bool NEE>
-__device__ __forceinline__ bool shade_one(const DevScene& S, const PathState& P, uint32_t slot, uint32_t depth, uint32_t k0, uint32_t k1,
-                                          LaneStack stk, unsigned long long* counters) {
-    const float4 h = P.hit[slot], ro = P.ro[slot], rd = P.rd[slot], tp = P.tp[slot];
-    const V3 o = xyz(ro), d = xyz(rd);
-    V3 transport = xyz(tp);
-    const uint32_t flags = __float_as_uint(tp.w);
+__device__ __forceinline__ bool shade_core(const DevScene& S, PathVals& pv, const HitVals& hv, uint32_t depth, uint32_t k0, uint32_t k1,
+                                           LaneStack stk, unsigned long long* counters, V3& radiance) {
+    const V3 o = pv.o, d = pv.d;
+    V3 transport = pv.transport;
+    const uint32_t flags = pv.flags;
     uint32_t it = flags & 0xffffu;
-    const uint32_t hbits = __float_as_uint(h.x);
+    const uint32_t hbits = hv.bits;
     const bool is_hit = hbits != PT_MISS;
     const uint32_t hslot = hbits & 0x7fffffffu;
     const bool inside = (hbits >> 31) != 0;
-    const float t = h.y;  // ray.distance after the trace
+    const float t = hv.t;  // ray.distance after the trace
     V3 acc = V3{0.f, 0.f, 0.f};
-    if (NEE) acc = xyz(P.acc[slot]);
+    if (NEE) acc = pv.acc;
+    const uint2 px = make_uint2(pv.pixel, pv.sample);
 
     if (flags & kPhaseBit) {
         // second half of the diffuse branch, camera.rs:361-372: the look-ahead trace has returned
-        const float cos_i = rd.w;
+        const float cos_i = pv.cos_i;
         float light_pdf = 0.0f;
         if (is_hit) {
             const uint32_t lm = prim_material<PRIM>(S, hslot);
             if (S.mats[lm].kind == PT_MAT_EMISSIVE) {
-                const Surface sf = surface_at<PRIM>(S, hslot, h.z, h.w, o, d, t, true);
+                const Surface sf = surface_at<PRIM>(S, hslot, hv.u, hv.v, o, d, t, true);
                 const float cos_l = -dot(sf.normal, d);
                 const float solid = (cos_l * sf.area) / (t * t);
                 light_pdf = 1.0f / solid;
@@ -679,31 +692,31 @@ __device__ __forceinline__ bool shade_one(const DevScene& S, const PathState& P,
         const float mis = light_pdf + hemi_pdf;
         transport = mul_ew(transport, (cos_i / mis) * brdf);
         it += 1;
-        if (it >= depth) { finish(P, slot, acc); return false; }
+        if (it >= depth) { radiance = acc; return false; }
         // the next iteration re-traces this ray with the shortened ray.distance (quirk Q3)
-        P.ro[slot] = make_float4(o.x, o.y, o.z, t);
-        P.tp[slot] = make_float4(transport.x, transport.y, transport.z, __uint_as_float(it));
+        pv.tmax = t;
+        pv.transport = transport;
+        pv.flags = it;
         return true;
     }
 
     if (!is_hit) {  // camera.rs:301-304
-        finish(P, slot, acc + mul_ew(transport, 0.1f * sky_lookup(S, d)));
+        radiance = acc + mul_ew(transport, 0.1f * sky_lookup(S, d));
         return false;
     }
     const V3 Pt = o + t * d;  // ray.intersection(), ray.rs:33-35
-    const Surface sf = surface_at<PRIM>(S, hslot, h.z, h.w, o, d, t, false);
+    const Surface sf = surface_at<PRIM>(S, hslot, hv.u, hv.v, o, d, t, false);
     const V3 normal = sf.normal;
     const pt_material m = S.mats[sf.mat];
     const V3 color = V3{m.rgb[0], m.rgb[1], m.rgb[2]};
     V3 nd;
 
     if (m.kind == PT_MAT_EMISSIVE) {  // camera.rs:308-311
-        finish(P, slot, acc + mul_ew(transport, color));
+        radiance = acc + mul_ew(transport, color);
         return false;
     } else if (m.kind == PT_MAT_DIFFUSE) {  // camera.rs:312-374
         const float speculaty = m.a;
-        if (inside) { finish(P, slot, acc); return false; }
-        const uint2 px = P.pxs[slot];
+        if (inside) { radiance = acc; return false; }
         if (NEE) {
             // camera.rs:314-338.  Its weight min(1 - speculaty, 0) is exactly 0 unless speculaty > 1,
             // and then the block adds nothing, so it only runs when the weight is non-zero.
@@ -795,14 +808,17 @@ __device__ __forceinline__ bool shade_one(const DevScene& S, const PathState& P,
             tm = tm > transport.z ? tm : transport.z;
             const float survival = fmax_(tm, 0.1f);
             if (rr < survival) transport = transport / survival;
-            else { finish(P, slot, acc); return false; }
+            else { radiance = acc; return false; }
             nd = cosine_weighted_diffuse(normal, closed01(r.v[2]), closed01(r.v[3]));
             const V3 no = advance(Pt, nd);
             const float cos_i = dot(nd, normal);
-            P.ro[slot] = make_float4(no.x, no.y, no.z, kInf);
-            P.rd[slot] = make_float4(nd.x, nd.y, nd.z, cos_i);
-            P.tp[slot] = make_float4(transport.x, transport.y, transport.z, __uint_as_float(it | kPhaseBit | (sf.mat << kMatShift)));
-            if (NEE) P.acc[slot] = make_float4(acc.x, acc.y, acc.z, 0.f);
+            pv.o = no;
+            pv.d = nd;
+            pv.tmax = kInf;
+            pv.cos_i = cos_i;
+            pv.transport = transport;
+            pv.flags = it | kPhaseBit | (sf.mat << kMatShift);
+            if (NEE) pv.acc = acc;
             return true;
         }
     } else {  // Dielectric, camera.rs:375-417
@@ -816,7 +832,6 @@ __device__ __forceinline__ bool shade_one(const DevScene& S, const PathState& P,
         V3 refr;
         if (refract(d, nf, na, nb, &refr)) {
             const float sr = schlick(d, nf, na, nb);
-            const uint2 px = P.pxs[slot];
             const U4 r = philox4x32_10(k0, k1, px.x, px.y, 1u + it, 0u);
             if (closed01(r.v[0]) < sr) {
                 if (!inside) transport = mul_ew(transport, color);
@@ -830,14 +845,51 @@ __device__ __forceinline__ bool shade_one(const DevScene& S, const PathState& P,
     }
     // ray.reset(P, nd, inf) and on to the next iteration
     it += 1;
-    if (it >= depth) { finish(P, slot, acc); return false; }
-    const V3 no = advance(Pt, nd);
-    P.ro[slot] = make_float4(no.x, no.y, no.z, kInf);
-    P.rd[slot] = make_float4(nd.x, nd.y, nd.z, 0.0f);
-    P.tp[slot] = make_float4(transport.x, transport.y, transport.z, __uint_as_float(it));
-    if (NEE) P.acc[slot] = make_float4(acc.x, acc.y, acc.z, 0.f);
+    if (it >= depth) { radiance = acc; return false; }
+    pv.o = advance(Pt, nd);
+    pv.d = nd;
+    pv.tmax = kInf;
+    pv.cos_i = 0.0f;
+    pv.transport = transport;
+    pv.flags = it;
+    if (NEE) pv.acc = acc;
     return true;
 }
+
+// shade_core on a path whose state lives in HBM (the wavefront round kernel and the queue-fed tail kernel)
+template <int PRIM, bool NEE>
+__device__ __forceinline__ bool shade_one(const DevScene& S, const PathState& P, uint32_t slot, uint32_t depth, uint32_t k0, uint32_t k1,
+                                          LaneStack stk, unsigned long long* counters) {
+    const float4 h = P.hit[slot], ro = P.ro[slot], rd = P.rd[slot], tp = P.tp[slot];
+    const uint2 px = P.pxs[slot];
+    PathVals pv;
+    pv.o = xyz(ro);
+    pv.d = xyz(rd);
+    pv.tmax = ro.w;
+    pv.cos_i = rd.w;
+    pv.transport = xyz(tp);
+    pv.flags = __float_as_uint(tp.w);
+    pv.acc = V3{0.f, 0.f, 0.f};
+    if (NEE) pv.acc = xyz(P.acc[slot]);
+    pv.pixel = px.x;
+    pv.sample = px.y;
+    HitVals hv;
+    hv.bits = __float_as_uint(h.x);
+    hv.t = h.y;
+    hv.u = h.z;
+    hv.v = h.w;
+    V3 radiance;
+    if (!shade_core<PRIM, NEE>(S, pv, hv, depth, k0, k1, stk, counters, radiance)) {
+        P.out[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+        return false;
+    }
+    P.ro[slot] = make_float4(pv.o.x, pv.o.y, pv.o.z, pv.tmax);
+    P.rd[slot] = make_float4(pv.d.x, pv.d.y, pv.d.z, pv.cos_i);
+    P.tp[slot] = make_float4(pv.transport.x, pv.transport.y, pv.transport.z, __uint_as_float(pv.flags));
+    if (NEE) P.acc[slot] = make_float4(pv.acc.x, pv.acc.y, pv.acc.z, 0.f);
+    return true;
+}
+
 
 template <int PRIM, bool NEE>
 __global__ __launch_bounds__(kTraceBlock) void k_shade(DevScene S, PathState P, const uint32_t* __restrict__ q_in,
@@ -1006,6 +1058,115 @@ __global__ __launch_bounds__(kTraceBlock) void k_tail_pw(DevScene S, PathState P
     }
 }
 
+// k_path — the whole of generate() + sample() for a batch of paths in ONE persistent kernel, path
+// state in registers.  Lanes are idle, traversing, or waiting to be shaded (as in k_tail_pw), but
+//   * an idle lane takes the next path slot of the batch and generates its primary ray itself
+//     (Camera::generate), so there is no raygen pass, no ray queue and no compaction;
+//   * shade_core works on the lane's registers and puts the next ray straight back into traversal;
+//   * the only per-path HBM traffic is the 16-byte radiance written when the path ends.
+// slot -> (sample, pixel) is the same 8x8-tile order as the wavefront kernels, and every value is
+// computed by the same device functions, so the sums are bit-identical.
+template <int PRIM, bool NEE, bool COUNT>
+__global__ __launch_bounds__(kTraceBlock) void k_path(DevScene S, const DevCamera* __restrict__ camp, PixelMap M, uint32_t n_samples,
+                                                      uint32_t sample_base, uint32_t depth, uint32_t k0, uint32_t k1,
+                                                      float4* __restrict__ out, uint32_t* __restrict__ cursor, LaunchCfg cfg,
+                                                      unsigned long long* counters) {
+    __shared__ unsigned long long smem[kLdsStack * kTraceBlock];
+    LaneStack stk = make_stack(smem, cfg);
+    const DevCamera cam = *camp;
+    const uint32_t n = n_samples * M.npix_pad;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t nn = 0, np = 0, worst = 0, mine = 0, rays = 0, paths = 0;
+    LaneTrav T;
+    T.cur = 0; T.sp = 0; T.dist = 0.f; T.hslot = PT_MISS; T.hinside = 0; T.hu = T.hv = 0.f; T.slot = 0;
+    T.o = T.d = T.rcp = V3{0.f, 0.f, 0.f};
+    PathVals pv;
+    pv.o = pv.d = pv.transport = pv.acc = V3{0.f, 0.f, 0.f};
+    pv.tmax = pv.cos_i = 0.f;
+    pv.flags = pv.pixel = pv.sample = 0;
+    bool active = false, pending = false, drained = false;
+    uint32_t chunk_next = 0, chunk_end = 0;
+    const uint32_t per_wave = n / (gridDim.x * (kTraceBlock / 64)) + 1;
+    const uint32_t chunk = per_wave >= (uint32_t)kFetchChunk ? (uint32_t)kFetchChunk : (per_wave < 64u ? 64u : (per_wave & ~63u));
+    while (true) {
+        const unsigned long long pend = __ballot(pending);
+        const unsigned long long act = __ballot(active);
+        if (pend != 0 && (__popcll(pend) >= kShadeLanes || act == 0)) {
+            if (pending) {
+                pending = false;
+                HitVals hv;
+                hv.bits = T.hslot == PT_MISS ? PT_MISS : (T.hslot | (T.hinside << 31));
+                hv.t = T.dist;
+                hv.u = T.hu;
+                hv.v = T.hv;
+                pv.o = T.o;
+                pv.d = T.d;
+                V3 radiance;
+                if (shade_core<PRIM, NEE>(S, pv, hv, depth, k0, k1, stk, counters, radiance)) {
+                    rays += 1;
+                    active = lane_start_ray<COUNT>(S, T, make_float4(pv.o.x, pv.o.y, pv.o.z, pv.tmax), make_float4(pv.d.x, pv.d.y, pv.d.z, 0.f), nn, mine);
+                    pending = !active;  // a ray that misses the root box is shaded as a miss
+                } else {
+                    out[T.slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+                }
+            }
+            continue;
+        }
+        const unsigned long long idle = __ballot(!active && !pending);
+        const int n_idle = __popcll(idle);
+        if (!drained && n_idle >= kRefillLanes) {
+            if (!wave_fetch_chunk(cursor, n, chunk, chunk_next, chunk_end)) drained = true;
+            if (!active && !pending && !drained) {
+                const uint32_t idx = chunk_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                if (idx < chunk_end) {
+                    const uint32_t s_local = idx / M.npix_pad, pix_idx = idx - s_local * M.npix_pad;
+                    uint32_t x, y;
+                    if (map_pixel(M, pix_idx, &x, &y)) {
+                        T.slot = idx;
+                        V3 o, d;
+                        const uint32_t sample = sample_base + s_local;
+                        generate_ray(cam, x, y, sample, k0, k1, &o, &d);
+                        pv.transport = V3{1.f, 1.f, 1.f};
+                        pv.flags = 0;
+                        pv.cos_i = 0.f;
+                        pv.acc = V3{0.f, 0.f, 0.f};
+                        pv.pixel = y * M.width + x;
+                        pv.sample = sample;
+                        paths += 1;
+                        if (depth == 0) {  // `for _ in 0..0`: the sample is (0,0,0) and nothing is traced
+                            out[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        } else {
+                            rays += 1;
+                            active = lane_start_ray<COUNT>(S, T, make_float4(o.x, o.y, o.z, kInf), make_float4(d.x, d.y, d.z, 0.f), nn, mine);
+                            pending = !active;
+                        }
+                    }
+                }
+            }
+            chunk_next = chunk_next + (uint32_t)n_idle < chunk_end ? chunk_next + (uint32_t)n_idle : chunk_end;
+            continue;
+        }
+        if (act == 0) {
+            if (drained) break;
+            continue;
+        }
+        phase_internal<COUNT>(S, T, active, stk, __popcll(act), nn, mine);
+        phase_leaf<PRIM, COUNT>(S, T, active, stk, np);
+        if (!active && ((act >> lane) & 1ull)) {
+            pending = true;
+            if (COUNT) worst = mine > worst ? mine : worst;
+        }
+    }
+    wave_add(counters + CNT_PATHS, paths);
+    wave_add(counters + CNT_RAYS_CLOSEST, rays);
+    wave_add(counters + CNT_TAIL_RAYS, rays);
+    if (COUNT) {
+        wave_add(counters + CNT_TAIL_NODE_TESTS, nn);
+        wave_add(counters + CNT_TAIL_PRIM_TESTS, np);
+        reduce_worst(counters, worst);
+    }
+}
+
 // chunk[idx] += sample, src/main.rs:159 — samples of one pixel are added in sample order, so the
 // sum is the one the reference's frame loop builds one frame at a time.
 __global__ __launch_bounds__(256) void k_accumulate(PixelMap M, const float4* __restrict__ out, uint32_t n_samples, float* __restrict__ accum) {
@@ -1121,6 +1282,22 @@ void launch_tail(int prim, bool nee, bool count, int mode, const DevScene& S, co
     if (mode == 2) { PT_TAIL_ALL(k_tail) } else { PT_TAIL_ALL(k_tail_pw) }
 #undef PT_TAIL_ALL
 #undef PT_TAIL
+}
+
+void launch_path(int prim, bool nee, bool count, const DevScene& S, const DevCamera* cam, const PixelMap& M, uint32_t n_samples,
+                 uint32_t sample_base, uint32_t depth, uint32_t k0, uint32_t k1, float4* out, uint32_t* cursor, const LaunchCfg& cfg,
+                 unsigned long long* counters, hipStream_t st) {
+    const uint64_t total = (uint64_t)n_samples * M.npix_pad;
+    const uint32_t grid = blocks_for(total, kTraceBlock, cfg.grid);
+#define PT_PATH(PR, N, C) hipLaunchKernelGGL((k_path<PR, N, C>), dim3(grid), dim3(kTraceBlock), 0, st, S, cam, M, n_samples, sample_base, depth, k0, k1, out, cursor, cfg, counters)
+    if (prim == PRIM_TRIANGLE) {
+        if (nee) { if (count) PT_PATH(PRIM_TRIANGLE, true, true); else PT_PATH(PRIM_TRIANGLE, true, false); }
+        else { if (count) PT_PATH(PRIM_TRIANGLE, false, true); else PT_PATH(PRIM_TRIANGLE, false, false); }
+    } else {
+        if (nee) { if (count) PT_PATH(PRIM_SPHERE, true, true); else PT_PATH(PRIM_SPHERE, true, false); }
+        else { if (count) PT_PATH(PRIM_SPHERE, false, true); else PT_PATH(PRIM_SPHERE, false, false); }
+    }
+#undef PT_PATH
 }
 
 void launch_accumulate(const PixelMap& M, const float4* out, uint32_t n_samples, float* accum, hipStream_t st) {

@@ -349,6 +349,11 @@ def test_scheduling_does_not_change_results(ptcore, pairs, name):
         dict(batch=2 * W * H, lanes=2, tail_min=1 << 30, tail_frac=1),  # tail kernel takes over after 3 rounds
         dict(batch=W * H, lanes=3, tail_min=64, tail_frac=8),
         dict(batch=3 * W * H, lanes=2, tail_min=0, tail_frac=0, simple=1),  # one-ray-per-lane traversal kernel
+        dict(batch=2 * W * H, lanes=3, tail_min=1 << 30, tail_frac=1, tail_mode=2),  # lock-step fused tail kernel
+        dict(batch=2 * W * H, lanes=3, tail_min=1 << 30, tail_frac=1, first=1),     # tail kernel right after the primary rays
+        dict(batch=2 * W * H, lanes=3, tail_min=1 << 30, tail_frac=1, first=0),     # tail kernel does everything from the queue
+        dict(batch=2 * W * H, lanes=3, tail_min=0, tail_frac=0, mode=1),            # k_path: one persistent kernel, state in registers
+        dict(batch=1 << 23, lanes=2, tail_min=0, tail_frac=0, mode=1),
         dict(batch=1 << 23, lanes=1, tail_min=65536, tail_frac=16),    # defaults
     ]
     try:
@@ -358,6 +363,9 @@ def test_scheduling_does_not_change_results(ptcore, pairs, name):
             g.set_option(ptcore.OPT_TAIL_MIN_PATHS, cfg["tail_min"])
             g.set_option(ptcore.OPT_TAIL_FRACTION, cfg["tail_frac"])
             g.set_option(ptcore.OPT_SIMPLE_EXTEND, cfg.get("simple", 0))
+            g.set_option(ptcore.OPT_RENDER_MODE, cfg.get("mode", 0))
+            g.set_option(ptcore.OPT_TAIL_MODE, cfg.get("tail_mode", 0))
+            g.set_option(ptcore.OPT_FIRST_CHECK_ROUND, cfg.get("first", 3))
             g.set_camera(cam_o, cam_t, W, H)
             g.reset_counters()
             g.render(spp, 32, seed=21)
@@ -371,3 +379,6 @@ def test_scheduling_does_not_change_results(ptcore, pairs, name):
         g.set_option(ptcore.OPT_TAIL_MIN_PATHS, 65536)
         g.set_option(ptcore.OPT_TAIL_FRACTION, 16)
         g.set_option(ptcore.OPT_SIMPLE_EXTEND, 0)
+        g.set_option(ptcore.OPT_RENDER_MODE, 0)
+        g.set_option(ptcore.OPT_TAIL_MODE, 0)
+        g.set_option(ptcore.OPT_FIRST_CHECK_ROUND, 3)
