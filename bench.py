@@ -4,17 +4,21 @@
 
 A "step" is one pass of the hot path over one batch: `--spp` samples per pixel of the named
 workload (default C3: 871 414-triangle glass statue on a diffuse floor, 1920x1080, depth 32)
-rendered by pt_render (raygen -> extend/shade rounds -> accumulate).  Scene, BVH and sky are
+rendered by pt_render (default: the persistent path kernel k_path — raygen, traversal, shading
+and the bounce loop in one launch per batch — then accumulate; `--mode wavefront` selects the
+raygen -> extend/shade rounds -> fused tail variant).  Scene, BVH and sky are
 resident in HBM before the timed region.  For N > 1 (one process per GPU, torch.distributed over
 RCCL) every rank renders its own sample indices of the whole frame (sample sharding, weak
 scaling: per-GPU work is fixed) and the partial sums are combined by ONE reduce to rank 0 at
 readout, inside the timed region.  value = rays traced by all ranks / max-over-ranks time.
 
 Extra objects on the JSON line:
-  roofline     the traversal kernel (k_extend) against the HBM roof: algorithmic bytes
-               B_ray = 32 * node_tests + 36 * prim_tests + 28 + 12 per ray (the
-               counts come from an instrumented, untimed replay of the very same steps) divided
-               by the HIP-event time of the k_extend launches of the timed region.
+  roofline     the dominant kernel (k_path; k_extend in wavefront mode) against the HBM roof:
+               algorithmic bytes B_ray = 32 * node_tests + 36 * prim_tests + 28 + 12 per ray plus,
+               for k_path, B_shade = 100 B per bounce + 36 B per path (the counts
+               come from an instrumented, untimed replay of the very same steps) divided by the
+               HIP-event time of that kernel's launches in the timed region.  `traffic` is the
+               L2-miss traffic per launch from rocprofv3 PMC passes (profiles/r1_traffic.json).
   cpu_baseline the CPU oracle (a C++ restatement of the reference, kind "port") in the
                reference's threading mode on this box's host cores, on a bounded sample.
 """
@@ -85,7 +89,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="C3", choices=list(WORKLOADS))
-    ap.add_argument("--spp", type=int, default=64, help="samples per pixel per step")
+    ap.add_argument("--spp", type=int, default=256, help="samples per pixel per step")
+    ap.add_argument("--mode", default="path", choices=["path", "wavefront"], help="pt_render scheduling (same results)")
     ap.add_argument("--depth", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-replay", action="store_true")
@@ -105,6 +110,7 @@ def main():
     sky = scenes.make_sky()
     g = ptcore.PathTracer(device).set_scene(scene, sky)
     g.set_camera(cam_o, cam_t, W, H)
+    g.set_option(ptcore.OPT_RENDER_MODE, 1 if args.mode == "path" else 0)
     seed = 2026
     spp = args.spp
 
@@ -129,13 +135,21 @@ def main():
         run_steps(args.warmup, args.steps, ptcore.RENDER_COUNT)
         c = g.counters()
         rays_replay = c["rays_closest"] + c["rays_any"]
-        # the round kernel (k_extend) alone: rays finished by the fused tail kernel are not its work
-        ext_rays = rays_replay - c["tail_rays"]
-        ext_nodes = c["node_tests"] - c["tail_node_tests"]
-        ext_prims = c["prim_tests"] - c["tail_prim_tests"]
-        bytes_total = 32 * ext_nodes + 36 * ext_prims + (28 + 12) * ext_rays
-        nodes_per_ray = ext_nodes / max(ext_rays, 1)
-        prims_per_ray = ext_prims / max(ext_rays, 1)
+        if args.mode == "path":
+            # k_path does everything: every ray's traversal bytes plus the shading bytes of SURVEY 8d.
+            # bounces (shaded hits) >= rays - paths: every ray after a path's first needs a hit before it.
+            k_rays, k_nodes, k_prims = rays_replay, c["node_tests"], c["prim_tests"]
+            bounces = max(rays_replay - c["paths"], 0)
+            shade_bytes = 100 * bounces + 36 * c["paths"]
+        else:
+            # the round kernel (k_extend) alone: rays finished by the fused tail kernel are not its work
+            k_rays = rays_replay - c["tail_rays"]
+            k_nodes = c["node_tests"] - c["tail_node_tests"]
+            k_prims = c["prim_tests"] - c["tail_prim_tests"]
+            shade_bytes = 0
+        bytes_total = 32 * k_nodes + 36 * k_prims + (28 + 12) * k_rays + shade_bytes
+        nodes_per_ray = k_nodes / max(k_rays, 1)
+        prims_per_ray = k_prims / max(k_rays, 1)
         tail_share = c["tail_rays"] / max(rays_replay, 1)
 
     # ---- warmup + timed region
@@ -173,20 +187,30 @@ def main():
             "mpaths_per_s": paths_all / dt_max / 1e6,
             "rays_per_path": rays_all / max(paths_all, 1),
         }
-        if bytes_total is not None and c["extend_ms"] > 0:
-            launches = max(c["extend_launches"], 1)
-            achieved = bytes_total / (c["extend_ms"] * 1e-3) / 1e9
+        k_ms = c["tail_ms"] if args.mode == "path" else c["extend_ms"]
+        if bytes_total is not None and k_ms > 0:
+            launches = max(c["tail_launches"] if args.mode == "path" else c["extend_launches"], 1)
+            achieved = bytes_total / (k_ms * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
+            if os.path.exists(tpath):
+                with open(tpath) as f:
+                    tj = json.load(f)
+                key = f"{args.workload}:{args.mode}:{spp}:{args.depth}"
+                if key in tj:
+                    traffic = tj[key]["bytes_per_launch"]
             out["roofline"] = {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "kernel": "k_extend", "launches": launches,
-                "avg_launch_ms": c["extend_ms"] / launches, "bytes_per_launch": bytes_total / launches,
-                "bytes_per_ray": bytes_total / max(ext_rays, 1), "node_tests_per_ray": nodes_per_ray,
-                "prim_tests_per_ray": prims_per_ray, "kernel_rays": ext_rays,
-                "kernel_mrays_per_s": ext_rays / (c["extend_ms"] * 1e-3) / 1e6,
-                "note": "event times of launches that overlap other batches' kernels on the GPU; rays finished by the "
-                        "fused tail kernel (k_tail) are excluded from this kernel's bytes",
+                "traffic": traffic, "kernel": "k_path" if args.mode == "path" else "k_extend", "launches": launches,
+                "avg_launch_ms": k_ms / launches, "bytes_per_launch": bytes_total / launches,
+                "bytes_per_ray": bytes_total / max(k_rays, 1), "node_tests_per_ray": nodes_per_ray,
+                "prim_tests_per_ray": prims_per_ray, "kernel_rays": k_rays,
+                "kernel_mrays_per_s": k_rays / (k_ms * 1e-3) / 1e6,
+                "note": "HBM roof as the contract asks; the kernel's real limiters are VALU issue and memory latency "
+                        "(divergent 64-B node fetches served by L2 / Infinity Cache), see DESIGN.md and profiles/",
             }
-            out["tail"] = {"share_of_rays": tail_share, "launches": c["tail_launches"], "ms_total": c["tail_ms"]}
+            if args.mode != "path":
+                out["tail"] = {"share_of_rays": tail_share, "launches": c["tail_launches"], "ms_total": c["tail_ms"]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, sky, cam_o, cam_t, W, H, args.depth)
         print(json.dumps(out), flush=True)

@@ -185,14 +185,15 @@ int pt_trace(pt_ctx *ctx, const pt_ray *rays, uint64_t n, int any_hit, pt_hit *h
 int pt_sample_skybox(pt_ctx *ctx, const float *dirs, uint64_t n, float *rgb);
 
 /* Scheduling knobs of pt_render (no counterpart in the reference; none of them changes a result):
- *  PT_OPT_BATCH_PATHS     paths kept in flight per batch (default 8 Mi; whole samples per batch)
+ *  PT_OPT_BATCH_PATHS     paths per batch, whole samples (0 = default: 512 Mi in mode 1, 8 Mi in mode 0)
  *  PT_OPT_LANES           batches in flight at once, 1..8 (default 8)
  *  PT_OPT_TAIL_MIN_PATHS  a batch is handed to the fused tail kernel when at most this many paths
  *  PT_OPT_TAIL_FRACTION   ... or at most batch/fraction paths are still alive (0 = never)
  *  PT_OPT_TAIL_STREAMS    streams the tail kernels are spread over, 1..4 (default 4)
  *  PT_OPT_TAIL_PATHS_PER_LANE  paths each tail-kernel lane works through on average (default 4)
  *  PT_OPT_BULK_STREAMS    streams the round kernels of the lanes are spread over, 1..8 (default 8)
- *  PT_OPT_RENDER_MODE     0 = wavefront rounds + tail kernel, 1 = one persistent kernel per batch (k_path)
+ *  PT_OPT_RENDER_MODE     1 = one persistent kernel per batch, path state in registers (k_path, default),
+ *                         0 = wavefront rounds (raygen, extend, shade + compaction) + fused tail kernel
  *  PT_OPT_FIRST_CHECK_ROUND  rounds enqueued before the live-path count is first looked at (default 3)
  *  PT_OPT_TAIL_MODE       0 = fused phase-scheduled tail kernel, 1 = further rounds on the tail stream with a small
  *                         grid, 2 = fused tail kernel that traces and shades in lock step

@@ -33,7 +33,8 @@ struct DevBuf {
 
 constexpr uint32_t kMaxMaterials = 1u << 15;   // material id must fit the 15 bits saved across a look-ahead
 constexpr uint32_t kMaxDepth = 0xffffu;        // iteration counter has 16 bits
-constexpr uint64_t kTargetSlots = 8u << 20;    // paths kept in flight per batch (about 8.4 M)
+constexpr uint64_t kTargetSlots = 8u << 20;    // wavefront mode: paths kept in flight per batch (about 8.4 M, 112 B of state each)
+constexpr uint64_t kPathBatchSlots = 512u << 20;  // path-kernel mode: paths per launch (16 B each); measured: the larger the better
 constexpr uint64_t kMaxSlots = 1ull << 31;
 constexpr uint32_t kMaxLanes = 8;              // batches in flight (one HIP stream + path-state set each)
 constexpr uint64_t kTailMinPaths = 65536;      // hand a batch to the fused tail kernel below this many live paths ...
@@ -98,7 +99,7 @@ struct pt_ctx {
     DevBuf d_counters;
     double extend_ms = 0, render_ms = 0, tail_ms = 0;
     uint64_t extend_launches = 0, tail_launches = 0;
-    uint64_t opt_batch_slots = kTargetSlots, opt_tail_min = kTailMinPaths, opt_tail_fraction = kTailFraction, opt_lanes = kMaxLanes, opt_tail_streams = 4, opt_tail_paths_per_lane = 4, opt_first_check = 3, opt_simple_extend = 0, opt_bulk_streams = kMaxLanes, opt_tail_mode = 0, opt_render_mode = 0;
+    uint64_t opt_batch_slots = 0 /* 0 = the mode's default */, opt_tail_min = kTailMinPaths, opt_tail_fraction = kTailFraction, opt_lanes = kMaxLanes, opt_tail_streams = 4, opt_tail_paths_per_lane = 4, opt_first_check = 3, opt_simple_extend = 0, opt_bulk_streams = kMaxLanes, opt_tail_mode = 0, opt_render_mode = 1;
     std::vector<uint32_t> round_sizes;  // queue length of every round of the last finished batch
 
     int fail(int code, const std::string& msg) {
@@ -176,10 +177,10 @@ int pt_create(int device, pt_ctx** out) {
         pt_destroy(c);
         return PT_ERR_HIP;
     }
-    // persistent traversal grid: the LDS stacks (kLdsStack * 8 B per lane) allow 6 workgroups of 256 per CU
-    const uint32_t lds_per_block = kLdsStack * kTraceBlock * 8;
-    uint32_t per_cu = std::min<uint32_t>(8, (160u * 1024u) / lds_per_block);
-    c->cfg.grid = (uint32_t)c->num_cu * per_cu;
+    // persistent traversal grid: the LDS stacks (kLdsStack * 8 B per lane) bound the waves a CU can hold
+    const uint32_t lds_per_wave = kLdsStack * 64 * 8;
+    const uint32_t waves_per_cu = std::min<uint32_t>(kWavesPerCU, (160u * 1024u) / lds_per_wave);
+    c->cfg.grid = std::max<uint32_t>(1, (uint32_t)c->num_cu * waves_per_cu / (kTraceBlock / 64));
     c->cfg.spill = nullptr;
     c->cfg.spill_stride = c->cfg.grid * kTraceBlock;
     *out = c;
@@ -778,7 +779,8 @@ int pt_render(pt_ctx* c, uint32_t spp, uint32_t max_depth, uint64_t seed, const 
         return PT_OK;
     }
 
-    uint64_t per_batch = std::max<uint64_t>(1, c->opt_batch_slots / M.npix_pad);
+    const uint64_t want_slots = c->opt_batch_slots ? c->opt_batch_slots : (c->opt_render_mode == 1 ? kPathBatchSlots : kTargetSlots);
+    uint64_t per_batch = std::max<uint64_t>(1, want_slots / M.npix_pad);
     per_batch = std::min<uint64_t>(per_batch, spp);
     if (per_batch * M.npix_pad >= kMaxSlots) return c->fail(PT_ERR_LIMIT, "pt_render: batch too large");
     const uint64_t batch_slots = per_batch * M.npix_pad;
@@ -987,7 +989,7 @@ int pt_get_round_stats(pt_ctx* c, uint32_t* queue_sizes, uint32_t cap, uint32_t*
 int pt_set_option(pt_ctx* c, int option, uint64_t value) {
     if (!c) return PT_ERR_INVALID;
     switch (option) {
-        case PT_OPT_BATCH_PATHS: c->opt_batch_slots = std::max<uint64_t>(value, 64); return PT_OK;
+        case PT_OPT_BATCH_PATHS: c->opt_batch_slots = value ? std::max<uint64_t>(value, 64) : 0; return PT_OK;
         case PT_OPT_LANES: c->opt_lanes = std::min<uint64_t>(std::max<uint64_t>(value, 1), kMaxLanes); return PT_OK;
         case PT_OPT_TAIL_MIN_PATHS: c->opt_tail_min = value; return PT_OK;
         case PT_OPT_TAIL_FRACTION: c->opt_tail_fraction = value; return PT_OK;

@@ -57,8 +57,18 @@ struct LaunchCfg {
     uint32_t spill_stride;  // grid * block
 };
 
-constexpr int kTraceBlock = 256;  // threads per traversal workgroup
-constexpr int kLdsStack = 12;     // stack entries per lane kept in LDS
+#ifndef PT_TRACE_BLOCK
+#define PT_TRACE_BLOCK 64
+#endif
+#ifndef PT_LDS_STACK
+#define PT_LDS_STACK 12
+#endif
+#ifndef PT_WAVES_PER_CU
+#define PT_WAVES_PER_CU 24
+#endif
+constexpr int kTraceBlock = PT_TRACE_BLOCK;  // threads per traversal workgroup
+constexpr int kLdsStack = PT_LDS_STACK;      // stack entries per lane kept in LDS
+constexpr int kWavesPerCU = PT_WAVES_PER_CU; // persistent grid: waves launched per CU (what fits is decided by LDS and VGPRs)
 
 // parity seams
 void launch_trace(int prim, bool any_hit, bool count, const DevScene& S, const pt_ray* rays, uint64_t n, pt_hit* hits,

@@ -26,6 +26,12 @@
 
 #pragma clang fp contract(off)
 
+// k_path: 6 waves per SIMD (80 VGPRs, the shading temporaries spill) measured faster than 4 waves
+// without spills: the kernel lives on latency hiding.
+#ifndef PT_PATH_ATTR
+#define PT_PATH_ATTR __attribute__((amdgpu_waves_per_eu(6, 6)))
+#endif
+
 namespace pt {
 
 __device__ __forceinline__ V3 xyz(float4 v) { return V3{v.x, v.y, v.z}; }
@@ -1067,7 +1073,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_tail_pw(DevScene S, PathState P
 // slot -> (sample, pixel) is the same 8x8-tile order as the wavefront kernels, and every value is
 // computed by the same device functions, so the sums are bit-identical.
 template <int PRIM, bool NEE, bool COUNT>
-__global__ __launch_bounds__(kTraceBlock) void k_path(DevScene S, const DevCamera* __restrict__ camp, PixelMap M, uint32_t n_samples,
+__global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, const DevCamera* __restrict__ camp, PixelMap M, uint32_t n_samples,
                                                       uint32_t sample_base, uint32_t depth, uint32_t k0, uint32_t k1,
                                                       float4* __restrict__ out, uint32_t* __restrict__ cursor, LaunchCfg cfg,
                                                       unsigned long long* counters) {

@@ -87,7 +87,7 @@ def load() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: build it with `make -C pathtracer_amd/csrc` "
                               "(or __graft_entry__.build()); there is no CPU fallback")
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(os.environ.get("PTCORE_LIB", LIB_PATH))  # PTCORE_LIB: A/B builds of the same ABI
         lib.pt_strerror.restype = C.c_char_p
         lib.pt_last_error.restype = C.c_char_p
         lib.pt_last_error.argtypes = [C.c_void_p]

@@ -354,7 +354,8 @@ def test_scheduling_does_not_change_results(ptcore, pairs, name):
         dict(batch=2 * W * H, lanes=3, tail_min=1 << 30, tail_frac=1, first=0),     # tail kernel does everything from the queue
         dict(batch=2 * W * H, lanes=3, tail_min=0, tail_frac=0, mode=1),            # k_path: one persistent kernel, state in registers
         dict(batch=1 << 23, lanes=2, tail_min=0, tail_frac=0, mode=1),
-        dict(batch=1 << 23, lanes=1, tail_min=65536, tail_frac=16),    # defaults
+        dict(batch=1 << 23, lanes=1, tail_min=65536, tail_frac=16),    # wavefront defaults
+        dict(batch=0, lanes=8, tail_min=65536, tail_frac=16, mode=1),  # defaults
     ]
     try:
         for cfg in configs:
@@ -374,11 +375,11 @@ def test_scheduling_does_not_change_results(ptcore, pairs, name):
             orays = orays or rays
             assert rays == orays, cfg
     finally:
-        g.set_option(ptcore.OPT_BATCH_PATHS, 1 << 23)
+        g.set_option(ptcore.OPT_BATCH_PATHS, 0)
         g.set_option(ptcore.OPT_LANES, 8)
         g.set_option(ptcore.OPT_TAIL_MIN_PATHS, 65536)
         g.set_option(ptcore.OPT_TAIL_FRACTION, 16)
         g.set_option(ptcore.OPT_SIMPLE_EXTEND, 0)
-        g.set_option(ptcore.OPT_RENDER_MODE, 0)
+        g.set_option(ptcore.OPT_RENDER_MODE, 1)
         g.set_option(ptcore.OPT_TAIL_MODE, 0)
         g.set_option(ptcore.OPT_FIRST_CHECK_ROUND, 3)
