@@ -955,6 +955,12 @@ int pt_get_counters(pt_ctx* c, pt_counters* out) {
     PT_HIP(c, hipSetDevice(c->device));
     unsigned long long cur[CNT_N];
     PT_HIP(c, hipMemcpy(cur, c->d_counters.p, sizeof(cur), hipMemcpyDeviceToHost));
+    if (std::getenv("PTCORE_PHASE_STATS")) {  // filled by -DPT_PHASE_STATS builds only
+        static const char* names[6] = {"shade", "generate", "internal", "leaf", "leaf(traversing)", "lifetime"};
+        for (int i = 0; i < 6; ++i)
+            std::fprintf(stderr, "[ptcore] phase %-16s exec %14llu lanes %16llu clocks %16llu\n", names[i], cur[CNT_PHASE + 3 * i],
+                         cur[CNT_PHASE + 3 * i + 1], cur[CNT_PHASE + 3 * i + 2]);
+    }
     out->paths = cur[CNT_PATHS];
     out->rays_closest = cur[CNT_RAYS_CLOSEST];
     out->rays_any = cur[CNT_RAYS_ANY];

@@ -49,7 +49,9 @@ struct PathState {
 
 // CNT_NODE_TESTS / CNT_PRIM_TESTS are the round kernels' (k_extend, k_trace); the fused tail kernel keeps its own
 enum { CNT_PATHS = 0, CNT_RAYS_CLOSEST, CNT_RAYS_ANY, CNT_NODE_TESTS, CNT_PRIM_TESTS, CNT_MAX_NODE_TESTS, CNT_TAIL_RAYS,
-       CNT_TAIL_NODE_TESTS, CNT_TAIL_PRIM_TESTS, CNT_N };
+       CNT_TAIL_NODE_TESTS, CNT_TAIL_PRIM_TESTS,
+       CNT_PHASE,  // diagnostics of a -DPT_PHASE_STATS build: 6 phases x {executions, lanes, clocks}
+       CNT_N = CNT_PHASE + 18 };
 
 struct LaunchCfg {
     uint32_t grid;          // workgroups of the persistent traversal launch

@@ -460,9 +460,26 @@ __device__ __forceinline__ bool lane_pop(LaneTrav& T, const LaneStack& stk) {
     return false;
 }
 
-constexpr int kRefillLanes = 20;     // refill when at least this many lanes of the wave are idle
-constexpr int kFetchChunk = 256;     // rays a wave reserves per atomic on the queue cursor
-constexpr int kShadeLanes = 16;      // fused kernel: shade when at least this many lanes wait for it
+#ifndef PT_REFILL_LANES
+#define PT_REFILL_LANES 20
+#endif
+#ifndef PT_SHADE_LANES
+#define PT_SHADE_LANES 16
+#endif
+#ifndef PT_INTERNAL_EXIT_DEN
+#define PT_INTERNAL_EXIT_DEN 4
+#endif
+constexpr int kRefillLanes = PT_REFILL_LANES;  // refill when at least this many lanes of the wave are idle
+constexpr int kFetchChunk = 256;               // rays a wave reserves per atomic on the queue cursor
+constexpr int kShadeLanes = PT_SHADE_LANES;    // fused kernels: shade when at least this many lanes wait for it
+#ifndef PT_STEP_BIAS_NUM
+#define PT_STEP_BIAS_NUM 1
+#endif
+#ifndef PT_STEP_BIAS_DEN
+#define PT_STEP_BIAS_DEN 1
+#endif
+constexpr int kStepBiasNum = PT_STEP_BIAS_NUM, kStepBiasDen = PT_STEP_BIAS_DEN;  // k_path: internal step when n_int * NUM >= n_leaf * DEN
+constexpr int kInternalExitDen = PT_INTERNAL_EXIT_DEN;  // leave the internal phase when at most 1/DEN of the traversing lanes still descend
 
 // load a ray into a lane and do the root test; false = the ray misses the whole scene
 template <bool COUNT>
@@ -484,35 +501,117 @@ __device__ __forceinline__ bool lane_start_ray(const DevScene& S, LaneTrav& T, f
     return false;
 }
 
-// internal phase: lanes at internal nodes step until at most a quarter of the traversing lanes still descend
+// Diagnostics (-DPT_PHASE_STATS builds only): per phase, wave-level executions, lanes that took part, clocks.
+struct PhaseStats {
+    unsigned long long exec[6], lanes[6], clk[6];
+    __device__ __forceinline__ void init() { for (int i = 0; i < 6; ++i) exec[i] = lanes[i] = clk[i] = 0; }
+    __device__ __forceinline__ void add(int p, unsigned long long mask, unsigned long long t0) {
+#ifdef PT_PHASE_STATS
+        exec[p] += 1;
+        lanes[p] += (unsigned long long)__popcll(mask);
+        clk[p] += __builtin_amdgcn_s_memtime() - t0;
+#endif
+    }
+    __device__ __forceinline__ unsigned long long now() const {
+#ifdef PT_PHASE_STATS
+        return __builtin_amdgcn_s_memtime();
+#else
+        return 0;
+#endif
+    }
+    __device__ __forceinline__ void flush(unsigned long long* counters) const {
+#ifdef PT_PHASE_STATS
+        if ((threadIdx.x & 63u) == 0)
+            for (int i = 0; i < 6; ++i) {
+                atomicAdd(counters + CNT_PHASE + 3 * i, exec[i]);
+                atomicAdd(counters + CNT_PHASE + 3 * i + 1, lanes[i]);
+                atomicAdd(counters + CNT_PHASE + 3 * i + 2, clk[i]);
+            }
+#endif
+    }
+};
+
+// one internal-node step of one lane (bvh.rs:198-222): test both children, descend into the nearer, push the farther
+template <bool COUNT>
+__device__ __forceinline__ void step_internal(const DevScene& S, LaneTrav& T, bool& active, const LaneStack& stk, uint32_t& nn, uint32_t& mine) {
+    const float4* rec = S.pairs + (size_t)T.cur * 4;
+    const float4 a = rec[0], b = rec[1], c = rec[2], e = rec[3];
+    float tl, tr;
+    const bool hl = slab(a.x, a.y, a.z, b.x, b.y, b.z, T.o, T.rcp, T.dist, &tl);
+    const bool hr = slab(c.x, c.y, c.z, e.x, e.y, e.z, T.o, T.rcp, T.dist, &tr);
+    if (COUNT) { nn += 2; mine += 2; }
+    const uint32_t lref = __float_as_uint(a.w), rref = __float_as_uint(c.w);
+    if (hl && hr) {
+        const bool left_first = tl <= tr;  // bvh.rs:211
+        stk.put(T.sp, left_first ? rref : lref, left_first ? tr : tl);
+        T.sp += 1;
+        T.cur = left_first ? lref : rref;
+    } else if (hl) {
+        T.cur = lref;
+    } else if (hr) {
+        T.cur = rref;
+    } else if (!lane_pop(T, stk)) {
+        active = false;
+    }
+}
+
+// one primitive of a leaf against the lane's ray; an accepted hit replaces the previous one (last accepted wins)
+template <int PRIM>
+__device__ __forceinline__ void test_prim(const DevScene& S, LaneTrav& T, uint32_t ps) {
+    if (PRIM == PRIM_TRIANGLE) {
+        const float4* tp = S.prim + (size_t)ps * 3;
+        const float4 a = tp[0], b = tp[1], c = tp[2];
+        float t, u, v, det;
+        if (tri_hit(V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, V3{b.z, b.w, c.x}, T.o, T.d, &t, &u, &v, &det)) {
+            T.dist = t;  // unconditionally, triangle.rs:72
+            T.hslot = ps;
+            T.hu = u;
+            T.hv = v;
+            T.hinside = det < 0.0f ? 1u : 0u;
+        }
+    } else {
+        const float4 sp4 = S.prim[ps];
+        float t;
+        bool inside;
+        if (sphere_hit(V3{sp4.x, sp4.y, sp4.z}, sp4.w, T.o, T.d, T.dist, &t, &inside)) {
+            T.dist = t;
+            T.hslot = ps;
+            T.hinside = inside ? 1u : 0u;
+        }
+    }
+}
+
+// One primitive step of a lane that stands at a leaf: test the leaf's next primitive; the leaf
+// reference itself is the cursor (first += 1, count -= 1), the lane pops after the last one.
+// Leaves of more than 31 primitives (count field 0) are rare and done in one go.
+template <int PRIM, bool COUNT>
+__device__ __forceinline__ void step_prim(const DevScene& S, LaneTrav& T, bool& active, const LaneStack& stk, uint32_t& np) {
+    const uint32_t first = T.cur & kLeafFirstMask;
+    const uint32_t count = (T.cur >> kLeafCountShift) & 31u;
+    bool done;
+    if (count == 0) {
+        const uint32_t bf = S.big_leaf[2 * first], bc = S.big_leaf[2 * first + 1];
+        if (COUNT) np += bc;
+        for (uint32_t k = 0; k < bc; ++k) test_prim<PRIM>(S, T, bf + k);
+        done = true;
+    } else {
+        if (COUNT) np += 1;
+        test_prim<PRIM>(S, T, first);
+        done = count == 1;
+        T.cur = T.cur + 1u - (1u << kLeafCountShift);
+    }
+    if (done && !lane_pop(T, stk)) active = false;
+}
+
+// internal phase: lanes at internal nodes step until at most 1/kInternalExitDen of the traversing lanes still descend
 template <bool COUNT>
 __device__ __forceinline__ void phase_internal(const DevScene& S, LaneTrav& T, bool& active, const LaneStack& stk, int n_act, uint32_t& nn,
                                                uint32_t& mine) {
     while (true) {
         const bool at_internal = active && !(T.cur & kLeafBit);
         const unsigned long long m = __ballot(at_internal);
-        if (m == 0 || (__popcll(m) * 4 <= n_act && __popcll(m) != n_act)) break;
-        if (at_internal) {
-            const float4* rec = S.pairs + (size_t)T.cur * 4;
-            const float4 a = rec[0], b = rec[1], c = rec[2], e = rec[3];
-            float tl, tr;
-            const bool hl = slab(a.x, a.y, a.z, b.x, b.y, b.z, T.o, T.rcp, T.dist, &tl);
-            const bool hr = slab(c.x, c.y, c.z, e.x, e.y, e.z, T.o, T.rcp, T.dist, &tr);
-            if (COUNT) { nn += 2; mine += 2; }
-            const uint32_t lref = __float_as_uint(a.w), rref = __float_as_uint(c.w);
-            if (hl && hr) {
-                const bool left_first = tl <= tr;  // bvh.rs:211
-                stk.put(T.sp, left_first ? rref : lref, left_first ? tr : tl);
-                T.sp += 1;
-                T.cur = left_first ? lref : rref;
-            } else if (hl) {
-                T.cur = lref;
-            } else if (hr) {
-                T.cur = rref;
-            } else if (!lane_pop(T, stk)) {
-                active = false;
-            }
-        }
+        if (m == 0 || (__popcll(m) * kInternalExitDen <= n_act && __popcll(m) != n_act)) break;
+        if (at_internal) step_internal<COUNT>(S, T, active, stk, nn, mine);
     }
 }
 
@@ -527,30 +626,7 @@ __device__ __forceinline__ void phase_leaf(const DevScene& S, LaneTrav& T, bool&
             first = S.big_leaf[2 * first];
         }
         if (COUNT) np += count;
-        for (uint32_t k = 0; k < count; ++k) {
-            const uint32_t ps = first + k;
-            if (PRIM == PRIM_TRIANGLE) {
-                const float4* tp = S.prim + (size_t)ps * 3;
-                const float4 a = tp[0], b = tp[1], c = tp[2];
-                float t, u, v, det;
-                if (tri_hit(V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, V3{b.z, b.w, c.x}, T.o, T.d, &t, &u, &v, &det)) {
-                    T.dist = t;  // unconditionally, triangle.rs:72
-                    T.hslot = ps;
-                    T.hu = u;
-                    T.hv = v;
-                    T.hinside = det < 0.0f ? 1u : 0u;
-                }
-            } else {
-                const float4 sp4 = S.prim[ps];
-                float t;
-                bool inside;
-                if (sphere_hit(V3{sp4.x, sp4.y, sp4.z}, sp4.w, T.o, T.d, T.dist, &t, &inside)) {
-                    T.dist = t;
-                    T.hslot = ps;
-                    T.hinside = inside ? 1u : 0u;
-                }
-            }
-        }
+        for (uint32_t k = 0; k < count; ++k) test_prim<PRIM>(S, T, first + k);
         if (!lane_pop(T, stk)) active = false;
     }
 }
@@ -1092,12 +1168,16 @@ __global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, c
     pv.flags = pv.pixel = pv.sample = 0;
     bool active = false, pending = false, drained = false;
     uint32_t chunk_next = 0, chunk_end = 0;
+    PhaseStats st;
+    st.init();
+    const unsigned long long t_begin = st.now();
     const uint32_t per_wave = n / (gridDim.x * (kTraceBlock / 64)) + 1;
     const uint32_t chunk = per_wave >= (uint32_t)kFetchChunk ? (uint32_t)kFetchChunk : (per_wave < 64u ? 64u : (per_wave & ~63u));
     while (true) {
         const unsigned long long pend = __ballot(pending);
         const unsigned long long act = __ballot(active);
         if (pend != 0 && (__popcll(pend) >= kShadeLanes || act == 0)) {
+            const unsigned long long t0 = st.now();
             if (pending) {
                 pending = false;
                 HitVals hv;
@@ -1116,11 +1196,13 @@ __global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, c
                     out[T.slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
                 }
             }
+            st.add(0, pend, t0);
             continue;
         }
         const unsigned long long idle = __ballot(!active && !pending);
         const int n_idle = __popcll(idle);
         if (!drained && n_idle >= kRefillLanes) {
+            const unsigned long long t0 = st.now();
             if (!wave_fetch_chunk(cursor, n, chunk, chunk_next, chunk_end)) drained = true;
             if (!active && !pending && !drained) {
                 const uint32_t idx = chunk_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
@@ -1150,19 +1232,41 @@ __global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, c
                 }
             }
             chunk_next = chunk_next + (uint32_t)n_idle < chunk_end ? chunk_next + (uint32_t)n_idle : chunk_end;
+            st.add(1, idle, t0);
             continue;
         }
         if (act == 0) {
             if (drained) break;
             continue;
         }
-        phase_internal<COUNT>(S, T, active, stk, __popcll(act), nn, mine);
-        phase_leaf<PRIM, COUNT>(S, T, active, stk, np);
-        if (!active && ((act >> lane) & 1ull)) {
-            pending = true;
-            if (COUNT) worst = mine > worst ? mine : worst;
+        // Traversal steps until enough lanes wait for shading or for a new path.  Each step the wave
+        // does whichever kind (internal node / leaf primitive) more of its lanes are waiting for.
+        // This is the hot loop: it is an inner loop of its own so that register allocation favours it.
+        while (true) {
+            const unsigned long long actv = __ballot(active);
+            if (actv == 0) break;
+            const int n_wait = __popcll(__ballot(pending));
+            if (n_wait >= kShadeLanes) break;
+            if (!drained && 64 - __popcll(actv) - n_wait >= kRefillLanes) break;
+            const bool at_internal = active && !(T.cur & kLeafBit);
+            const unsigned long long mi = __ballot(at_internal);
+            const int n_int = __popcll(mi), n_leaf = __popcll(actv) - n_int;
+            const unsigned long long t0 = st.now();
+            if (n_int * kStepBiasNum >= n_leaf * kStepBiasDen) {
+                if (at_internal) step_internal<COUNT>(S, T, active, stk, nn, mine);
+                st.add(2, mi, t0);
+            } else {
+                if (active && !at_internal) step_prim<PRIM, COUNT>(S, T, active, stk, np);
+                st.add(3, actv & ~mi, t0);
+            }
+            if (!active && ((actv >> lane) & 1ull)) {
+                pending = true;
+                if (COUNT) worst = mine > worst ? mine : worst;
+            }
         }
     }
+    st.add(5, ~0ull, t_begin);  // wave lifetime
+    st.flush(counters);
     wave_add(counters + CNT_PATHS, paths);
     wave_add(counters + CNT_RAYS_CLOSEST, rays);
     wave_add(counters + CNT_TAIL_RAYS, rays);
