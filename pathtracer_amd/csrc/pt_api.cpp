@@ -735,7 +735,7 @@ static int lane_tail(pt_ctx* c, RenderLane& L, const RenderJob& J, uint32_t live
 // All paths of the batch are finished and the previous batch has been added: add this batch's samples.
 static int lane_accumulate(pt_ctx* c, RenderLane& L, const RenderJob& J) {
     hipStream_t ts = c->tail_stream[L.batch % c->opt_tail_streams];
-    launch_accumulate(J.M, L.ps.out, L.ns, (float*)c->d_accum.p, ts);
+    launch_accumulate(J.M, L.ps.out, L.ns, c->opt_render_mode == 1, (float*)c->d_accum.p, ts);
     PT_HIP(c, hipEventRecord(L.ev_done, ts));
     PT_HIP(c, hipGetLastError());
     c->last_acc_event = L.ev_done;
@@ -956,7 +956,9 @@ int pt_get_counters(pt_ctx* c, pt_counters* out) {
     unsigned long long cur[CNT_N];
     PT_HIP(c, hipMemcpy(cur, c->d_counters.p, sizeof(cur), hipMemcpyDeviceToHost));
     if (std::getenv("PTCORE_PHASE_STATS")) {  // filled by -DPT_PHASE_STATS builds only
-        static const char* names[6] = {"shade", "generate", "internal", "leaf", "leaf(traversing)", "lifetime"};
+        static const char* names[6] = {"shade", "generate", "internal", "leaf", "drained", "lifetime"};
+        std::fprintf(stderr, "[ptcore] drained mode: most iterations of one wave %llu, longest drained time of one wave %llu clocks\n",
+                     cur[CNT_MAX_NODE_TESTS], cur[CNT_NODE_TESTS]);
         for (int i = 0; i < 6; ++i)
             std::fprintf(stderr, "[ptcore] phase %-16s exec %14llu lanes %16llu clocks %16llu\n", names[i], cur[CNT_PHASE + 3 * i],
                          cur[CNT_PHASE + 3 * i + 1], cur[CNT_PHASE + 3 * i + 2]);

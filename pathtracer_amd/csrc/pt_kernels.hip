@@ -1146,7 +1146,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_tail_pw(DevScene S, PathState P
 //     (Camera::generate), so there is no raygen pass, no ray queue and no compaction;
 //   * shade_core works on the lane's registers and puts the next ray straight back into traversal;
 //   * the only per-path HBM traffic is the 16-byte radiance written when the path ends.
-// slot -> (sample, pixel) is the same 8x8-tile order as the wavefront kernels, and every value is
+// slots are pixel-major (8x8-tile pixel order, then the samples of the pixel), and every value is
 // computed by the same device functions, so the sums are bit-identical.
 template <int PRIM, bool NEE, bool COUNT>
 __global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, const DevCamera* __restrict__ camp, PixelMap M, uint32_t n_samples,
@@ -1176,7 +1176,9 @@ __global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, c
     while (true) {
         const unsigned long long pend = __ballot(pending);
         const unsigned long long act = __ballot(active);
-        if (pend != 0 && (__popcll(pend) >= kShadeLanes || act == 0)) {
+        // once the batch has no more paths to hand out the wave only empties: from then on it runs
+        // for latency (shade at once, both kinds of traversal step every turn), not for full waves
+        if (pend != 0 && (__popcll(pend) >= kShadeLanes || act == 0 || drained)) {
             const unsigned long long t0 = st.now();
             if (pending) {
                 pending = false;
@@ -1207,7 +1209,9 @@ __global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, c
             if (!active && !pending && !drained) {
                 const uint32_t idx = chunk_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                 if (idx < chunk_end) {
-                    const uint32_t s_local = idx / M.npix_pad, pix_idx = idx - s_local * M.npix_pad;
+                    // pixel-major slots: the samples of a pixel are neighbours, so the lanes of a wave start
+                    // with (nearly) the same primary ray and walk the same nodes
+                    const uint32_t pix_idx = idx / n_samples, s_local = idx - pix_idx * n_samples;
                     uint32_t x, y;
                     if (map_pixel(M, pix_idx, &x, &y)) {
                         T.slot = idx;
@@ -1246,17 +1250,28 @@ __global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, c
             const unsigned long long actv = __ballot(active);
             if (actv == 0) break;
             const int n_wait = __popcll(__ballot(pending));
-            if (n_wait >= kShadeLanes) break;
+            if (n_wait >= kShadeLanes || (drained && n_wait != 0)) break;
             if (!drained && 64 - __popcll(actv) - n_wait >= kRefillLanes) break;
             const bool at_internal = active && !(T.cur & kLeafBit);
+            const bool at_leaf = active && !at_internal;
             const unsigned long long mi = __ballot(at_internal);
             const int n_int = __popcll(mi), n_leaf = __popcll(actv) - n_int;
-            const unsigned long long t0 = st.now();
-            if (n_int * kStepBiasNum >= n_leaf * kStepBiasDen) {
+            const bool internal_turn = n_int * kStepBiasNum >= n_leaf * kStepBiasDen;
+#ifdef PT_PHASE_STATS
+            if (drained) {
+                if (st.exec[4] == 0) st.clk[4] = st.now();  // becomes the time spent drained at flush
+                st.exec[4] += 1;
+                st.lanes[4] += (unsigned long long)(__popcll(actv) + n_wait);
+            }
+#endif
+            if (internal_turn || drained) {
+                const unsigned long long t0 = st.now();
                 if (at_internal) step_internal<COUNT>(S, T, active, stk, nn, mine);
                 st.add(2, mi, t0);
-            } else {
-                if (active && !at_internal) step_prim<PRIM, COUNT>(S, T, active, stk, np);
+            }
+            if (!internal_turn || drained) {
+                const unsigned long long t0 = st.now();
+                if (at_leaf) step_prim<PRIM, COUNT>(S, T, active, stk, np);
                 st.add(3, actv & ~mi, t0);
             }
             if (!active && ((actv >> lane) & 1ull)) {
@@ -1265,6 +1280,13 @@ __global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, c
             }
         }
     }
+#ifdef PT_PHASE_STATS
+    if (st.exec[4]) st.clk[4] = st.now() - st.clk[4];
+    if ((threadIdx.x & 63u) == 0) {
+        atomicMax(counters + CNT_MAX_NODE_TESTS, st.exec[4]);       // most drained-mode iterations of any wave
+        atomicMax(counters + CNT_NODE_TESTS, st.clk[4]);            // longest drained time of any wave (clocks)
+    }
+#endif
     st.add(5, ~0ull, t_begin);  // wave lifetime
     st.flush(counters);
     wave_add(counters + CNT_PATHS, paths);
@@ -1279,13 +1301,31 @@ __global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, c
 
 // chunk[idx] += sample, src/main.rs:159 — samples of one pixel are added in sample order, so the
 // sum is the one the reference's frame loop builds one frame at a time.
-__global__ __launch_bounds__(256) void k_accumulate(PixelMap M, const float4* __restrict__ out, uint32_t n_samples, float* __restrict__ accum) {
+__global__ __launch_bounds__(64) void k_accumulate(PixelMap M, const float4* __restrict__ out, uint32_t n_samples, int pixel_major,
+                                                    float* __restrict__ accum) {
     for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < M.npix_pad; idx += gridDim.x * blockDim.x) {
         uint32_t x, y;
         if (!map_pixel(M, idx, &x, &y)) continue;
         float* a = accum + ((size_t)y * M.width + x) * 3;
         V3 sum = ld3(a);
-        for (uint32_t s = 0; s < n_samples; ++s) sum = sum + xyz(out[(size_t)s * M.npix_pad + idx]);
+        // slab layout: [sample][pixel] from the wavefront kernels, [pixel][sample] from k_path
+        if (pixel_major) {
+            // a lane owns 16 * n_samples contiguous bytes: fetch a whole 128-byte line (8 samples) at a
+            // time so every line is asked for once, then add in sample order
+            const float4* src = out + (size_t)idx * n_samples;
+            uint32_t s = 0;
+            for (; s + 8 <= n_samples; s += 8) {
+                float4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = src[s + k];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sum = sum + xyz(v[k]);
+            }
+            for (; s < n_samples; ++s) sum = sum + xyz(src[s]);
+        } else {
+            const float4* src = out + idx;
+            for (uint32_t s = 0; s < n_samples; ++s) sum = sum + xyz(src[(size_t)s * M.npix_pad]);
+        }
         a[0] = sum.x;
         a[1] = sum.y;
         a[2] = sum.z;
@@ -1410,8 +1450,8 @@ void launch_path(int prim, bool nee, bool count, const DevScene& S, const DevCam
 #undef PT_PATH
 }
 
-void launch_accumulate(const PixelMap& M, const float4* out, uint32_t n_samples, float* accum, hipStream_t st) {
-    hipLaunchKernelGGL(k_accumulate, dim3(blocks_for(M.npix_pad, 256, 8192)), dim3(256), 0, st, M, out, n_samples, accum);
+void launch_accumulate(const PixelMap& M, const float4* out, uint32_t n_samples, bool pixel_major, float* accum, hipStream_t st) {
+    hipLaunchKernelGGL(k_accumulate, dim3(blocks_for(M.npix_pad, 64, 65536)), dim3(64), 0, st, M, out, n_samples, pixel_major ? 1 : 0, accum);
 }
 
 void launch_resolve(const float* accum, uint32_t width, uint32_t height, float scale, uint8_t* rgb, uint64_t pitch, hipStream_t st) {
