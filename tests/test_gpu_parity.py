@@ -383,3 +383,56 @@ def test_scheduling_does_not_change_results(ptcore, pairs, name):
         g.set_option(ptcore.OPT_RENDER_MODE, 1)
         g.set_option(ptcore.OPT_TAIL_MODE, 0)
         g.set_option(ptcore.OPT_FIRST_CHECK_ROUND, 3)
+
+
+def test_full_size_c3_workload(ptcore, orc, sky):
+    """BASELINE config C3 at its full size (871 414-triangle glass statue, 1920x1080, depth 32): the tree,
+    200 000 random traces and 4 000 random pixels of a 2-spp frame against the oracle bit for bit, and the
+    size-independent properties on the whole frame — both schedulings of pt_render give the same sums,
+    progressive frames add up to the one-shot frame, tile shards reassemble it."""
+    scene = scenes.statue_scene()
+    g = ptcore.PathTracer(0).set_scene(scene, sky)
+    o = orc.from_scene(scene, sky)
+    try:
+        gn, gi, gd = g.bvh()
+        on, oi, od = o.bvh()
+        assert gn.tobytes() == on.tobytes() and np.array_equal(gi, oi) and gd == od
+        rays = scenes.random_rays(200_000, seed=77)
+        assert_hits_equal(g.trace(rays), o.trace(rays))
+
+        W, H, depth, seed = 1920, 1080, 32, 5
+        g.set_camera(scenes.CAMERA_ORIGIN, scenes.CAMERA_TARGET, W, H)
+        o.set_camera(scenes.CAMERA_ORIGIN, scenes.CAMERA_TARGET, W, H)
+        gc, oc = g.camera(), o.camera()
+        for k in ("direction", "right", "up", "p1", "p2", "p3"):
+            assert gc[k].tobytes() == oc[k].tobytes(), k
+        assert gc["focal_distance"] == oc["focal_distance"]
+        g.render(2, depth, seed=seed)
+        full = g.read_accum()[0]
+        rng = np.random.default_rng(3)
+        xy = np.stack([rng.integers(0, W, 4000), rng.integers(0, H, 4000)], axis=1).astype(np.uint32)
+        xy[:500, 0] = rng.integers(W // 2 - 150, W // 2 + 150, 500)  # make sure the statue is well covered
+        xy[:500, 1] = rng.integers(H // 2 - 200, H // 2 + 200, 500)
+        want = o.sample_pixels(xy, 0, depth, seed, nee_mode=1) + o.sample_pixels(xy, 1, depth, seed, nee_mode=1)
+        got = full[xy[:, 1], xy[:, 0]]
+        assert got.tobytes() == want.astype(np.float32).tobytes()
+        assert np.abs(got).sum() > 0
+
+        g.set_option(ptcore.OPT_RENDER_MODE, 0)  # wavefront rounds + tail kernel
+        g.reset_accum()
+        g.render(2, depth, seed=seed)
+        assert g.read_accum()[0].tobytes() == full.tobytes()
+        g.set_option(ptcore.OPT_RENDER_MODE, 1)
+        g.reset_accum()
+        g.render(1, depth, seed=seed)
+        g.render(1, depth, seed=seed)
+        assert g.read_accum()[0].tobytes() == full.tobytes()
+        total = np.zeros_like(full)
+        for r in range(2):
+            g.reset_accum()
+            g.render(2, depth, seed=seed, shard=ptcore.Shard(ptcore.SHARD_TILES, r, 2, 64, 0))
+            total += g.read_accum()[0]
+        assert total.tobytes() == full.tobytes()
+    finally:
+        g.set_option(ptcore.OPT_RENDER_MODE, 1)
+        g.close()
