@@ -99,10 +99,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = "RANK" in os.environ  # launched by torch.distributed.run (also with one rank: same code path)
+    if use_dist:
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    device = local_rank if world > 1 else 0
+    device = local_rank if use_dist else 0
     torch.cuda.set_device(device)
 
     make, W, H, cam_o, cam_t, desc = WORKLOADS[args.workload]
@@ -124,7 +125,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -159,7 +160,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     run_steps(args.warmup, args.steps, ptcore.RENDER_TIMED)
-    if world > 1:
+    if use_dist:
         acc = torch.as_tensor(ptcore.AccumView(g), device=f"cuda:{device}")
         dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)  # readout: one collective per frame, not per bounce
     barrier()
@@ -170,7 +171,7 @@ def main():
 
     tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{device}")
     work = torch.tensor([rays, paths], dtype=torch.float64, device=f"cuda:{device}")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(work, op=dist.ReduceOp.SUM)
     dt_max = float(tt.item())
@@ -215,7 +216,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(scene, sky, cam_o, cam_t, W, H, args.depth)
         print(json.dumps(out), flush=True)
     g.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -436,3 +436,19 @@ def test_full_size_c3_workload(ptcore, orc, sky):
     finally:
         g.set_option(ptcore.OPT_RENDER_MODE, 1)
         g.close()
+
+
+def test_accumulator_is_shared_with_torch(ptcore, pairs):
+    """pt_accum_device_ptr / AccumView: torch wraps the device accumulator without a copy (this is what
+    the RCCL reduce of bench.py --gpus N operates on)."""
+    import torch
+    g, o, scene, cam_o, cam_t = pairs["cube"]
+    g.set_camera(cam_o, cam_t, 64, 48)
+    g.render(2, 8, seed=3)
+    want = g.read_accum()[0]
+    t = torch.as_tensor(ptcore.AccumView(g), device="cuda:0")
+    assert tuple(t.shape) == (48, 64, 3) and t.dtype == torch.float32
+    assert t.cpu().numpy().tobytes() == want.tobytes()
+    t += 1.0  # in place, on the library's own memory
+    torch.cuda.synchronize()
+    assert g.read_accum()[0].tobytes() == (want + np.float32(1.0)).tobytes()
