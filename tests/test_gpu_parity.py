@@ -452,3 +452,28 @@ def test_accumulator_is_shared_with_torch(ptcore, pairs):
     t += 1.0  # in place, on the library's own memory
     torch.cuda.synchronize()
     assert g.read_accum()[0].tobytes() == (want + np.float32(1.0)).tobytes()
+
+
+@pytest.mark.parametrize("name", ["C2", "C3"])
+def test_work_counters_match_committed_workloads(ptcore, sky, name):
+    """The algorithmic work bench.py prices (rays, node tests, primitive tests per config) is the oracle's:
+    tests/golden/workloads.json was written by the oracle's counters (make_workloads.py), and the device's
+    COUNT variant must report exactly the same numbers for the same frame."""
+    import json
+    with open(os.path.join(GOLD, "workloads.json")) as f:
+        w = json.load(f)[name]
+    scene = scenes.glass_cube_scene() if name == "C2" else scenes.statue_scene()
+    g = ptcore.PathTracer(0).set_scene(scene, sky)
+    try:
+        g.set_camera(scenes.CAMERA_ORIGIN, scenes.CAMERA_TARGET, w["width"], w["height"])
+        for mode in (1, 0):
+            g.set_option(ptcore.OPT_RENDER_MODE, mode)
+            g.reset_accum()
+            g.reset_counters()
+            g.render(w["spp"], w["max_depth"], seed=w["seed"], flags=ptcore.RENDER_COUNT)
+            c = g.counters()
+            got = {k: int(c[k]) for k in ("paths", "rays_closest", "rays_any", "node_tests", "prim_tests")}
+            assert got == {k: w[k] for k in got}, (mode, got)
+    finally:
+        g.set_option(ptcore.OPT_RENDER_MODE, 1)
+        g.close()

@@ -124,3 +124,25 @@ def test_tonemap(orc):
     assert orc.tonemap(0.01) == 38
     assert orc.tonemap(float("nan")) == 255
     assert orc.tonemap(-1.0) == 255  # sqrt(-1) = NaN -> min picks 255
+
+
+def test_committed_workload_counts_are_the_oracles(orc):
+    """tests/golden/workloads.json (the per-config work bench.py's roofline is priced with) is
+    reproducible from the oracle: recount C2, the cheap one (make_workloads.py regenerates all)."""
+    import json
+    import os
+    from pathtracer_amd import scenes
+    with open(os.path.join(os.path.dirname(__file__), "golden", "workloads.json")) as f:
+        w = json.load(f)
+    for name in ("C2", "C3", "C4"):
+        assert w[name]["paths"] == w[name]["width"] * w[name]["height"] * w[name]["spp"]
+        assert w[name]["rays_any"] == 0  # the shadow-ray weight is exactly 0 in these scenes (quirk Q2)
+    c2 = w["C2"]
+    o = orc.from_scene(scenes.glass_cube_scene(), scenes.make_sky())
+    o.set_camera(scenes.CAMERA_ORIGIN, scenes.CAMERA_TARGET, c2["width"], c2["height"])
+    o.reset_counters()
+    o.render(c2["spp"], c2["max_depth"], seed=c2["seed"], nthreads=4, nee_mode=1)
+    c = o.counters()
+    for k in ("paths", "rays_closest", "rays_any", "node_tests", "prim_tests"):
+        assert int(c[k]) == c2[k], k
+    o.close()
