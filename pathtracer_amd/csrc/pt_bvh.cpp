@@ -2,8 +2,11 @@
 // operation is the single IEEE-754 operation the Rust source performs.
 #include "pt_bvh.h"
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <limits>
+#include <thread>
 
 #pragma clang fp contract(off)
 
@@ -33,12 +36,38 @@ struct Box {
     }
 };
 
+// Parallel loop over [first, last) in contiguous pieces, one per thread (used on large nodes only).
+template <class F>
+void parallel_pieces(uint32_t first, uint32_t last, int threads, F&& body) {
+    const uint32_t n = last - first;
+    if (threads <= 1 || n < (1u << 16)) {
+        body(0, first, last);
+        return;
+    }
+    std::vector<std::thread> pool;
+    const uint32_t per = (n + (uint32_t)threads - 1) / (uint32_t)threads;
+    for (int t = 1; t < threads; ++t) {
+        const uint32_t a = first + std::min<uint64_t>((uint64_t)t * per, n), b = first + std::min<uint64_t>((uint64_t)(t + 1) * per, n);
+        pool.emplace_back([&body, t, a, b] { body(t, a, b); });
+    }
+    body(0, first, first + std::min(per, n));
+    for (std::thread& th : pool) th.join();
+}
+
+// One subtree, built in the reference's order.  `nodes` is local to the subtree: nodes[0] is a copy
+// of the subtree's root and child links are local indices, so subtrees can be built by different
+// threads and spliced together afterwards (the reference's explicit stack finishes a node's whole
+// subtree before it touches anything else, so a subtree's nodes are contiguous in its numbering).
+// `indices` is the shared bvh.indices array; a subtree only touches its own range of it.
 struct Builder {
     const std::vector<PrimInfo>& prims;
-    HostBVH& out;
-    std::vector<uint32_t> depth;  // level of each node
+    uint32_t* indices;
+    std::vector<pt_bvh_node> nodes;
+    uint32_t max_depth = 1;  // levels below and including this subtree's root
+    bool hazard = false;
+    int threads = 1;         // helper threads for the passes over one large node
 
-    Builder(const std::vector<PrimInfo>& p, HostBVH& o) : prims(p), out(o) {}
+    Builder(const std::vector<PrimInfo>& p, uint32_t* idx) : prims(p), indices(idx) {}
 
     // bvh.rs:104-169.  Returns false when no split beats the parent cost.
     bool choose_split(const pt_bvh_node& node, int* axis_out, float* pivot_out) const {
@@ -47,25 +76,46 @@ struct Builder {
         for (int a = 0; a < 3; ++a) { nb.lo[a] = node.min[a]; nb.hi[a] = node.max[a]; }
         const float parent_cost = nb.area() * (float)count;
 
-        Box cb;
-        cb.clear();
-        for (uint32_t i = first; i < first + count; ++i) cb.grow_point(prims[out.indices[i]].c);
+        // min / max / counts are order independent, so the pieces of a large node can be reduced in any order
+        const int nt = threads > 1 && count >= (1u << 16) ? threads : 1;
+        std::vector<Box> cbs((size_t)nt);
+        parallel_pieces(first, first + count, nt, [&](int t, uint32_t a, uint32_t b) {
+            Box cb;
+            cb.clear();
+            for (uint32_t i = a; i < b; ++i) cb.grow_point(prims[indices[i]].c);
+            cbs[(size_t)t] = cb;
+        });
+        Box cb = cbs[0];
+        for (int t = 1; t < nt; ++t) cb.grow(cbs[(size_t)t].lo, cbs[(size_t)t].hi);
         float delta[3];
         for (int a = 0; a < 3; ++a) delta[a] = (cb.hi[a] - cb.lo[a]) / 8.0f;
 
-        Box bin_box[24];
-        uint32_t bin_n[24];
-        for (int b = 0; b < 24; ++b) { bin_box[b].clear(); bin_n[b] = 0; }
-        for (uint32_t i = first; i < first + count; ++i) {
-            const PrimInfo& p = prims[out.indices[i]];
-            for (int a = 0; a < 3; ++a) {
-                // ((c - cmin) / delta).max(0.).min(7.) as usize  — NaN (0/0) becomes 0
-                float q = (p.c[a] - cb.lo[a]) / delta[a];
-                int b = a * 8 + (int)mn2(mx2(q, 0.0f), 7.0f);
-                bin_box[b].grow(p.mn, p.mx);
-                bin_n[b] += 1;
+        struct Bins {
+            Box box[24];
+            uint32_t n[24];
+        };
+        std::vector<Bins> parts((size_t)nt);
+        parallel_pieces(first, first + count, nt, [&](int t, uint32_t a0, uint32_t b0) {
+            Bins& B = parts[(size_t)t];
+            for (int b = 0; b < 24; ++b) { B.box[b].clear(); B.n[b] = 0; }
+            for (uint32_t i = a0; i < b0; ++i) {
+                const PrimInfo& p = prims[indices[i]];
+                for (int a = 0; a < 3; ++a) {
+                    // ((c - cmin) / delta).max(0.).min(7.) as usize  — NaN (0/0) becomes 0
+                    float q = (p.c[a] - cb.lo[a]) / delta[a];
+                    int b = a * 8 + (int)mn2(mx2(q, 0.0f), 7.0f);
+                    B.box[b].grow(p.mn, p.mx);
+                    B.n[b] += 1;
+                }
             }
-        }
+        });
+        Box* bin_box = parts[0].box;
+        uint32_t* bin_n = parts[0].n;
+        for (int t = 1; t < nt; ++t)
+            for (int b = 0; b < 24; ++b) {
+                bin_box[b].grow(parts[(size_t)t].box[b].lo, parts[(size_t)t].box[b].hi);
+                bin_n[b] += parts[(size_t)t].n[b];
+            }
 
         int best_axis = -1, best_bin = -1;
         float best = parent_cost;
@@ -98,11 +148,11 @@ struct Builder {
         return true;
     }
 
-    // bvh.rs:63-103
+    // bvh.rs:63-103.  The swap sequence decides the leaf order, so this pass stays sequential.
     bool partition(uint32_t ni) {
         int axis;
         float pivot;
-        const pt_bvh_node node = out.nodes[ni];
+        const pt_bvh_node node = nodes[ni];
         if (!choose_split(node, &axis, &pivot)) return false;
         const uint32_t first = node.left_first, count = node.count;
         Box lb, rb;
@@ -110,58 +160,93 @@ struct Builder {
         rb.clear();
         uint32_t split = first;
         for (uint32_t i = first; i < first + count; ++i) {
-            const PrimInfo& p = prims[out.indices[i]];
+            const PrimInfo& p = prims[indices[i]];
             if (p.c[axis] <= pivot) {
                 lb.grow(p.mn, p.mx);
-                uint32_t tmp = out.indices[split];
-                out.indices[split] = out.indices[i];
-                out.indices[i] = tmp;
+                uint32_t tmp = indices[split];
+                indices[split] = indices[i];
+                indices[i] = tmp;
                 split += 1;
             } else {
                 rb.grow(p.mn, p.mx);
             }
         }
-        const uint32_t left = (uint32_t)out.nodes.size();
-        out.nodes[ni].left_first = left;
-        out.nodes[ni].count = 0;
+        const uint32_t left = (uint32_t)nodes.size();
+        nodes[ni].left_first = left;
+        nodes[ni].count = 0;
         const uint32_t nl = split - first;
-        out.nodes.push_back(pt_bvh_node{{lb.lo[0], lb.lo[1], lb.lo[2]}, first, {lb.hi[0], lb.hi[1], lb.hi[2]}, nl});
-        out.nodes.push_back(pt_bvh_node{{rb.lo[0], rb.lo[1], rb.lo[2]}, split, {rb.hi[0], rb.hi[1], rb.hi[2]}, count - nl});
-        if (nl == 0 || nl == count) out.hazard = true;
+        nodes.push_back(pt_bvh_node{{lb.lo[0], lb.lo[1], lb.lo[2]}, first, {lb.hi[0], lb.hi[1], lb.hi[2]}, nl});
+        nodes.push_back(pt_bvh_node{{rb.lo[0], rb.lo[1], rb.lo[2]}, split, {rb.hi[0], rb.hi[1], rb.hi[2]}, count - nl});
+        if (nl == 0 || nl == count) hazard = true;
         return true;
     }
 
-    void run() {
-        const uint32_t n = (uint32_t)prims.size();
-        out.indices.resize(n);
-        Box root;
-        root.clear();
-        for (uint32_t i = 0; i < n; ++i) {
-            out.indices[i] = i;
-            root.grow(prims[i].mn, prims[i].mx);
-        }
-        out.nodes.clear();
-        out.nodes.reserve(2 * (size_t)n);
-        out.nodes.push_back(pt_bvh_node{{root.lo[0], root.lo[1], root.lo[2]}, 0, {root.hi[0], root.hi[1], root.hi[2]}, n});
-        depth.assign(1, 1);
-        out.max_depth = 1;
-        out.hazard = false;
-        // bvh.rs:52-62: explicit stack, left subtree first
+    // bvh.rs:52-62: explicit stack, left subtree first
+    void run(const pt_bvh_node& root) {
+        nodes.clear();
+        nodes.push_back(root);
+        std::vector<uint32_t> depth(1, 1);
+        max_depth = 1;
         std::vector<uint32_t> todo{0};
         while (!todo.empty()) {
             uint32_t ni = todo.back();
             todo.pop_back();
-            if (out.nodes[ni].count > 2 && partition(ni)) {
-                uint32_t left = out.nodes[ni].left_first;
-                depth.resize(out.nodes.size());
+            if (nodes[ni].count > 2 && partition(ni)) {
+                uint32_t left = nodes[ni].left_first;
+                depth.resize(nodes.size());
                 depth[left] = depth[left + 1] = depth[ni] + 1;
-                if (depth[left] > out.max_depth) out.max_depth = depth[left];
+                if (depth[left] > max_depth) max_depth = depth[left];
                 todo.push_back(left + 1);
                 todo.push_back(left);
             }
         }
     }
 };
+
+constexpr uint32_t kParallelMin = 8192;  // smaller subtrees are not worth a thread
+
+// Builds the subtree below `root` with up to `threads` threads.  Result: b.nodes[0] = root, then
+// the subtree's nodes in the reference's order with local child links.
+void build_subtree(const std::vector<PrimInfo>& prims, uint32_t* indices, const pt_bvh_node& root, int threads, Builder& b) {
+    if (threads <= 1 || root.count < kParallelMin) {
+        b.threads = 1;
+        b.run(root);
+        return;
+    }
+    // split this node here (its passes use all our threads), then build the two sides concurrently
+    b.threads = threads;
+    b.nodes.clear();
+    b.nodes.push_back(root);
+    b.max_depth = 1;
+    if (!(root.count > 2 && b.partition(0))) return;
+    const pt_bvh_node L = b.nodes[1], R = b.nodes[2];
+    Builder bl(prims, indices), br(prims, indices);
+    const uint64_t total = (uint64_t)L.count + R.count;
+    int tl = (int)((uint64_t)threads * L.count / (total ? total : 1));
+    tl = std::max(1, std::min(threads - 1, tl));
+    std::thread worker([&] { build_subtree(prims, indices, L, tl, bl); });
+    build_subtree(prims, indices, R, threads - tl, br);
+    worker.join();
+    // splice: [root, L, R, nodes below L..., nodes below R...]; an internal node's link moves with its block
+    const uint32_t nl = (uint32_t)bl.nodes.size() - 1, nr = (uint32_t)br.nodes.size() - 1;
+    b.nodes.resize(3 + (size_t)nl + nr);
+    b.nodes[1] = bl.nodes[0];
+    b.nodes[2] = br.nodes[0];
+    if (nl) b.nodes[1].left_first += 2;       // bl-local index 1 -> 3
+    if (nr) b.nodes[2].left_first += 2 + nl;  // br-local index 1 -> 3 + nl
+    for (uint32_t i = 0; i < nl; ++i) {
+        pt_bvh_node n = bl.nodes[1 + i];
+        if (n.count == 0) n.left_first += 2;
+        b.nodes[3 + i] = n;
+    }
+    for (uint32_t i = 0; i < nr; ++i) {
+        pt_bvh_node n = br.nodes[1 + i];
+        if (n.count == 0) n.left_first += 2 + nl;
+        b.nodes[3 + (size_t)nl + i] = n;
+    }
+    b.max_depth = 1 + std::max(bl.max_depth, br.max_depth);
+    b.hazard = b.hazard || bl.hazard || br.hazard;
+}
 
 }  // namespace
 
@@ -192,9 +277,26 @@ void prim_info_spheres(const float* cr, uint64_t n, std::vector<PrimInfo>& out) 
     }
 }
 
-void build_bvh(const std::vector<PrimInfo>& prims, HostBVH& out) {
-    Builder b(prims, out);
-    b.run();
+void build_bvh(const std::vector<PrimInfo>& prims, HostBVH& out, int threads) {
+    const uint32_t n = (uint32_t)prims.size();
+    out.indices.resize(n);
+    Box root;
+    root.clear();
+    for (uint32_t i = 0; i < n; ++i) {
+        out.indices[i] = i;
+        root.grow(prims[i].mn, prims[i].mx);
+    }
+    if (threads <= 0) {
+        const char* env = std::getenv("PTCORE_BUILD_THREADS");
+        threads = env ? std::atoi(env) : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+        if (threads < 1) threads = 1;
+    }
+    Builder b(prims, out.indices.data());
+    build_subtree(prims, out.indices.data(), pt_bvh_node{{root.lo[0], root.lo[1], root.lo[2]}, 0, {root.hi[0], root.hi[1], root.hi[2]}, n},
+                  threads, b);
+    out.nodes = std::move(b.nodes);
+    out.max_depth = b.max_depth;
+    out.hazard = b.hazard;
 }
 
 int flatten_bvh(const HostBVH& bvh, FlatBVH& out) {

@@ -31,7 +31,8 @@ struct HostBVH {
 
 void prim_info_triangles(const float* pos, uint64_t n, std::vector<PrimInfo>& out);
 void prim_info_spheres(const float* cr, uint64_t n, std::vector<PrimInfo>& out);
-void build_bvh(const std::vector<PrimInfo>& prims, HostBVH& out);
+// threads <= 0: PTCORE_BUILD_THREADS or min(16, hardware threads).  The tree does not depend on the thread count.
+void build_bvh(const std::vector<PrimInfo>& prims, HostBVH& out, int threads = 0);
 
 // Device references.  A child reference is one u32:
 //   bit 31 = 0 : internal node, bits 30..0 = index of its 64-byte child-pair record
