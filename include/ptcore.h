@@ -172,6 +172,10 @@ int pt_shard_map(uint32_t width, uint32_t height, uint32_t tile, uint32_t rank, 
 int pt_reset_accum(pt_ctx *ctx);
 /* accum: W x H x 3 floats, the running SUM (src/main.rs:100,159); spp_out: samples summed. */
 int pt_read_accum(pt_ctx *ctx, float *rgb, float *spp_out);
+/* Resume (the reference restarts from zero, src/main.rs:139-142): puts a sum read
+ * earlier with pt_read_accum back, with its sample count.  The next pt_render then continues with
+ * sample index (uint32)spp, so an interrupted and resumed run adds up to exactly the uninterrupted frame. */
+int pt_write_accum(pt_ctx *ctx, const float *rgb, float spp);
 /* vec_to_rgb(scale * accum) (src/main.rs:71-75,160-164) into an RGB24 image with row pitch. */
 int pt_read_rgb8(pt_ctx *ctx, uint8_t *rgb, uint64_t pitch_bytes);
 /* device address of the W x H x 3 float accumulator, for collectives that combine ranks. */

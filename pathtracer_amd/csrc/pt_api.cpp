@@ -917,6 +917,17 @@ int pt_read_accum(pt_ctx* c, float* rgb, float* spp_out) {
     return PT_OK;
 }
 
+int pt_write_accum(pt_ctx* c, const float* rgb, float spp) {
+    if (!c) return PT_ERR_INVALID;
+    if (!c->have_cam) return c->fail(PT_ERR_STATE, "pt_write_accum: no camera");
+    if (!rgb || !(spp >= 0.0f) || spp > 4294967040.0f) return c->fail(PT_ERR_INVALID, "pt_write_accum: null image or bad sample count");
+    PT_HIP(c, hipSetDevice(c->device));
+    PT_HIP(c, hipMemcpy(c->d_accum.p, rgb, (size_t)c->cam.width * c->cam.height * 3 * sizeof(float), hipMemcpyHostToDevice));
+    c->spp = spp;
+    c->samples_done = (uint32_t)spp;
+    return PT_OK;
+}
+
 int pt_read_rgb8(pt_ctx* c, uint8_t* rgb, uint64_t pitch) {
     if (!c) return PT_ERR_INVALID;
     if (!c->have_cam) return c->fail(PT_ERR_STATE, "pt_read_rgb8: no camera");

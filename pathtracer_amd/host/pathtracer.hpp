@@ -214,6 +214,13 @@ public:
         detail::check(ctx_, pt_read_accum(ctx_, rgb.data(), &spp), "pt_read_accum");
         return spp;
     }
+    // fp32 sum + sample count into caller memory (W*H*3 floats) / back (resume)
+    float read_accum(float* rgb) {
+        float spp = 0;
+        detail::check(ctx_, pt_read_accum(ctx_, rgb, &spp), "pt_read_accum");
+        return spp;
+    }
+    void write_accum(const float* rgb, float spp) { detail::check(ctx_, pt_write_accum(ctx_, rgb, spp), "pt_write_accum"); }
     const pt_camera_state& state() const { return state_; }
     const Scene<T>& scene() const { return scene_; }
     pt_ctx* context() { return ctx_; }

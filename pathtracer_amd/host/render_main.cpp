@@ -1,12 +1,17 @@
 // render_main.cpp — src/main.rs without SDL: builds a scene, runs the progressive frame loop on the
 // GPU through the C ABI and writes the tonemapped frame as a PPM.
-//   render [--spheres | --cube] [--size WxH] [--frames N] [--spp-per-frame K] [--sky file.raw] [--out frame.ppm]
+//   render [--spheres | --cube | --obj mesh.obj] [--size WxH] [--frames N] [--spp-per-frame K] [--sky file.raw]
+//          [--out frame.ppm] [--save-accum file] [--resume file] [--dump-mesh file]
+// --obj        Scene::scene(path) of src/scene.rs:35: load_mesh + light + floor (needs vertex normals)
+// --save-accum / --resume   fp32 accumulation dump and restart (W, H, spp header + W*H*3 floats)
+// --dump-mesh  write what load_mesh returned (24 floats per triangle) and exit; needs no GPU
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
 
+#include "mesh.hpp"
 #include "pathtracer.hpp"
 
 using namespace pt;
@@ -44,9 +49,28 @@ static std::vector<Triangle> cube_mesh(Material m) {
     return out;
 }
 
+struct AccumFile {
+    std::string save, resume;
+};
+
 template <class T>
-static int run(Camera<T>& camera, uint32_t W, uint32_t H, int frames, int spp, const std::string& out) {
+static int run(Camera<T>& camera, uint32_t W, uint32_t H, int frames, int spp, const std::string& out, const AccumFile& af) {
     std::vector<uint8_t> fb((size_t)W * H * 3);
+    std::vector<float> accum((size_t)W * H * 3);
+    if (!af.resume.empty()) {
+        FILE* f = std::fopen(af.resume.c_str(), "rb");
+        uint32_t hdr[2];
+        float done = 0.f;
+        if (!f || std::fread(hdr, 4, 2, f) != 2 || std::fread(&done, 4, 1, f) != 1 || hdr[0] != W || hdr[1] != H ||
+            std::fread(accum.data(), 4, accum.size(), f) != accum.size()) {
+            if (f) std::fclose(f);
+            std::fprintf(stderr, "cannot resume from %s (missing, truncated or another size)\n", af.resume.c_str());
+            return 1;
+        }
+        std::fclose(f);
+        camera.write_accum(accum.data(), done);
+        std::printf("resumed at %g spp\n", done);
+    }
     auto t0 = std::chrono::steady_clock::now();
     for (int f = 0; f < frames; ++f) {
         camera.render(spp, 32, 2026);   // spp += 1 per frame in the reference, main.rs:143
@@ -56,6 +80,16 @@ static int run(Camera<T>& camera, uint32_t W, uint32_t H, int frames, int spp, c
     pt_counters c = camera.counters();
     std::printf("%d frames x %d spp: %.1f ms/frame, %.1f Mrays/s, %.1f Mpaths/s, focal distance %g\n", frames, spp, dt * 1e3 / frames,
                 c.rays_closest / dt / 1e6, c.paths / dt / 1e6, camera.state().focal_distance);
+    if (!af.save.empty()) {
+        float done = camera.read_accum(accum.data());
+        FILE* f = std::fopen(af.save.c_str(), "wb");
+        if (!f) return 1;
+        uint32_t hdr[2] = {W, H};
+        std::fwrite(hdr, 4, 2, f);
+        std::fwrite(&done, 4, 1, f);
+        std::fwrite(accum.data(), 4, accum.size(), f);
+        std::fclose(f);
+    }
     FILE* f = std::fopen(out.c_str(), "wb");
     if (!f) return 1;
     std::fprintf(f, "P6\n%u %u\n255\n", W, H);
@@ -68,7 +102,8 @@ int main(int argc, char** argv) {
     uint32_t W = 800, H = 600;  // main.rs:77-78
     int frames = 16, spp = 1;
     bool spheres = false;
-    std::string out = "frame.ppm", sky_path;
+    std::string out = "frame.ppm", sky_path, obj_path, dump_path;
+    AccumFile af;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         if (a == "--spheres") spheres = true;
@@ -78,17 +113,40 @@ int main(int argc, char** argv) {
         else if (a == "--spp-per-frame" && i + 1 < argc) spp = std::atoi(argv[++i]);
         else if (a == "--sky" && i + 1 < argc) sky_path = argv[++i];
         else if (a == "--out" && i + 1 < argc) out = argv[++i];
+        else if (a == "--obj" && i + 1 < argc) obj_path = argv[++i];
+        else if (a == "--dump-mesh" && i + 1 < argc) dump_path = argv[++i];
+        else if (a == "--save-accum" && i + 1 < argc) af.save = argv[++i];
+        else if (a == "--resume" && i + 1 < argc) af.resume = argv[++i];
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
     try {
+        std::vector<Triangle> mesh;
+        if (!obj_path.empty()) mesh = load_mesh(obj_path, backup_glass());
+        if (!dump_path.empty()) {
+            FILE* f = std::fopen(dump_path.c_str(), "wb");
+            if (!f) return 1;
+            for (const Triangle& t : mesh) {
+                const Vec3* v[6] = {&t.position0, &t.position1, &t.position2, &t.normal0, &t.normal1, &t.normal2};
+                for (const Vec3* p : v) std::fwrite(p->data(), 4, 3, f);
+                const float m[6] = {(float)t.material.m.kind, t.material.m.a, t.material.m.b, t.material.m.rgb[0], t.material.m.rgb[1], t.material.m.rgb[2]};
+                std::fwrite(m, 4, 6, f);
+            }
+            std::fclose(f);
+            std::printf("%zu triangles\n", mesh.size());
+            return 0;
+        }
         std::vector<float> sky = sky_path.empty() ? synthetic_sky() : Scene<Sphere>::read_skybox(sky_path);
         if (spheres) {
             Camera<Sphere> camera(W, H, Scene<Sphere>::default_scene(std::move(sky)));
             camera.look_at({0.0f, 0.2f, 1.0f}, {0.0f, -0.2f, -2.0f});  // the default pose looks away from the spheres
-            return run(camera, W, H, frames, spp, out);
+            return run(camera, W, H, frames, spp, out, af);
+        }
+        if (!obj_path.empty()) {
+            Camera<Triangle> camera(W, H, Scene<Triangle>::scene(std::move(mesh), std::move(sky)));  // floor speculaty 0.5, scene.rs:63
+            return run(camera, W, H, frames, spp, out, af);
         }
         Camera<Triangle> camera(W, H, Scene<Triangle>::scene(cube_mesh(Material::dielectric(1.0f, 1.5f, {0.01f, 0.9f, 0.01f})), std::move(sky), 0.0f));
-        return run(camera, W, H, frames, spp, out);
+        return run(camera, W, H, frames, spp, out, af);
     } catch (const Error& e) {
         std::fprintf(stderr, "error %d: %s\n", e.status, e.what());
         return 1;

@@ -37,7 +37,7 @@ OPT_BATCH_PATHS, OPT_LANES, OPT_TAIL_MIN_PATHS, OPT_TAIL_FRACTION, OPT_TAIL_STRE
 EXPORTS = [
     "pt_strerror", "pt_last_error", "pt_create", "pt_destroy", "pt_set_triangles", "pt_set_spheres", "pt_set_materials",
     "pt_set_sky", "pt_build", "pt_set_bvh", "pt_bvh_build", "pt_get_bvh_sizes", "pt_get_bvh", "pt_set_camera", "pt_get_camera", "pt_generate", "pt_render",
-    "pt_shard_map", "pt_reset_accum", "pt_read_accum", "pt_read_rgb8", "pt_accum_device_ptr", "pt_add_external_samples", "pt_trace",
+    "pt_shard_map", "pt_reset_accum", "pt_read_accum", "pt_write_accum", "pt_read_rgb8", "pt_accum_device_ptr", "pt_add_external_samples", "pt_trace",
     "pt_sample_skybox", "pt_set_option", "pt_get_counters", "pt_get_round_stats", "pt_reset_counters",
 ]
 
@@ -250,6 +250,12 @@ class PathTracer:
         spp = C.c_float()
         self._ck(self.l.pt_read_accum(self.h, _ptr(out), C.byref(spp)))
         return out, spp.value
+
+    def write_accum(self, accum, spp):
+        """Put back a sum read earlier with read_accum (resume); rendering continues at sample int(spp)."""
+        a = np.ascontiguousarray(accum, np.float32)
+        assert a.shape == (self.height, self.width, 3)
+        self._ck(self.l.pt_write_accum(self.h, _ptr(a), C.c_float(spp)))
 
     def read_rgb8(self, pitch=None):
         pitch = pitch or self.width * 3

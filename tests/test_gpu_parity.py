@@ -477,3 +477,24 @@ def test_work_counters_match_committed_workloads(ptcore, sky, name):
     finally:
         g.set_option(ptcore.OPT_RENDER_MODE, 1)
         g.close()
+
+
+def test_resume_from_saved_accumulator(ptcore, pairs):
+    """pt_write_accum: a run stopped after 3 samples, saved, and resumed for 2 more
+    gives exactly the uninterrupted 5-sample sums (the sample index sequence continues)."""
+    g, o, scene, cam_o, cam_t = pairs["mesh"]
+    g.set_camera(cam_o, cam_t, 80, 56)
+    g.render(5, 32, seed=17)
+    full, spp = g.read_accum()
+    assert spp == 5.0
+    g.reset_accum()
+    g.render(3, 32, seed=17)
+    part, spp3 = g.read_accum()
+    g.set_camera(cam_o, cam_t, 80, 56)  # a fresh start: accumulator and sample counter are zeroed
+    assert not g.read_accum()[0].any()
+    g.write_accum(part, spp3)
+    g.render(2, 32, seed=17)
+    got, spp5 = g.read_accum()
+    assert spp5 == 5.0 and got.tobytes() == full.tobytes()
+    with pytest.raises(ptcore.PtError):
+        g.write_accum(part, -1.0)
