@@ -478,6 +478,13 @@ constexpr int kShadeLanes = PT_SHADE_LANES;    // fused kernels: shade when at l
 #ifndef PT_STEP_BIAS_DEN
 #define PT_STEP_BIAS_DEN 1
 #endif
+#ifndef PT_PATH_REFILL_LANES
+#define PT_PATH_REFILL_LANES 8
+#endif
+#ifndef PT_PATH_SHADE_LANES
+#define PT_PATH_SHADE_LANES 20
+#endif
+constexpr int kPathRefillLanes = PT_PATH_REFILL_LANES, kPathShadeLanes = PT_PATH_SHADE_LANES;  // k_path's own thresholds (swept on C3)
 constexpr int kStepBiasNum = PT_STEP_BIAS_NUM, kStepBiasDen = PT_STEP_BIAS_DEN;  // k_path: internal step when n_int * NUM >= n_leaf * DEN
 constexpr int kInternalExitDen = PT_INTERNAL_EXIT_DEN;  // leave the internal phase when at most 1/DEN of the traversing lanes still descend
 
@@ -1178,7 +1185,7 @@ __global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, c
         const unsigned long long act = __ballot(active);
         // once the batch has no more paths to hand out the wave only empties: from then on it runs
         // for latency (shade at once, both kinds of traversal step every turn), not for full waves
-        if (pend != 0 && (__popcll(pend) >= kShadeLanes || act == 0 || drained)) {
+        if (pend != 0 && (__popcll(pend) >= kPathShadeLanes || act == 0 || drained)) {
             const unsigned long long t0 = st.now();
             if (pending) {
                 pending = false;
@@ -1203,7 +1210,7 @@ __global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, c
         }
         const unsigned long long idle = __ballot(!active && !pending);
         const int n_idle = __popcll(idle);
-        if (!drained && n_idle >= kRefillLanes) {
+        if (!drained && n_idle >= kPathRefillLanes) {
             const unsigned long long t0 = st.now();
             if (!wave_fetch_chunk(cursor, n, chunk, chunk_next, chunk_end)) drained = true;
             if (!active && !pending && !drained) {
@@ -1250,8 +1257,8 @@ __global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, c
             const unsigned long long actv = __ballot(active);
             if (actv == 0) break;
             const int n_wait = __popcll(__ballot(pending));
-            if (n_wait >= kShadeLanes || (drained && n_wait != 0)) break;
-            if (!drained && 64 - __popcll(actv) - n_wait >= kRefillLanes) break;
+            if (n_wait >= kPathShadeLanes || (drained && n_wait != 0)) break;
+            if (!drained && 64 - __popcll(actv) - n_wait >= kPathRefillLanes) break;
             const bool at_internal = active && !(T.cur & kLeafBit);
             const bool at_leaf = active && !at_internal;
             const unsigned long long mi = __ballot(at_internal);
