@@ -498,3 +498,43 @@ def test_resume_from_saved_accumulator(ptcore, pairs):
     assert spp5 == 5.0 and got.tobytes() == full.tobytes()
     with pytest.raises(ptcore.PtError):
         g.write_accum(part, -1.0)
+
+
+def test_leaves_with_more_than_31_primitives(ptcore, orc, sky):
+    """SAH refuses to split coincident primitives (bvh.rs:56,158-162), so a leaf can hold any number of
+    them; leaves above 31 go through the device's big-leaf table.  40 copies of one glass triangle
+    and 35 of a diffuse one inside a small mesh: same tree, same hits (the LAST accepted copy wins,
+    quirk Q1), same image sums, in both schedulings."""
+    pos, nrm, mat_id, mats = scenes.small_mesh_scene()
+    glass = np.tile(np.array([[0.2, -0.1, 0.4, 1.1, -0.1, 0.5, 0.6, 0.9, 0.45]], np.float32), (40, 1))
+    matte = np.tile(np.array([[1.4, -0.3, 0.2, 1.4, 0.6, 0.9, 1.5, -0.3, 1.2]], np.float32), (35, 1))
+    extra = np.concatenate([glass, matte])
+    extra_n = np.tile(np.array([[0, 0, 1] * 3], np.float32), (len(extra), 1))
+    floor_id = int(mat_id[-1])
+    glass_id = int(mat_id[0])
+    scene = (np.concatenate([pos, extra]), np.concatenate([nrm, extra_n]),
+             np.concatenate([mat_id, np.full(40, glass_id, np.uint32), np.full(35, floor_id, np.uint32)]), mats)
+    g = ptcore.PathTracer(0).set_scene(scene, sky)
+    o = orc.from_scene(scene, sky)
+    try:
+        gn, gi, gd = g.bvh()
+        on, oi, od = o.bvh()
+        assert gn.tobytes() == on.tobytes() and np.array_equal(gi, oi)
+        assert (gn["count"] > 31).sum() >= 2
+        rays = scenes.random_rays(50_000, seed=8)
+        for any_hit in (False, True):
+            assert_hits_equal(g.trace(rays, any_hit), o.trace(rays, any_hit))
+        hit = g.trace(rays)["prim"]
+        assert np.isin(hit, np.arange(len(pos), len(pos) + 75)).sum() > 100  # the stacks of copies are really hit
+        W, H = 96, 64
+        o.set_camera(scenes.CAMERA_ORIGIN, scenes.CAMERA_TARGET, W, H)
+        o.render(3, 32, seed=4, nee_mode=1)
+        want = o.read_accum()[0]
+        for mode in (1, 0):
+            g.set_option(ptcore.OPT_RENDER_MODE, mode)
+            g.set_camera(scenes.CAMERA_ORIGIN, scenes.CAMERA_TARGET, W, H)
+            g.render(3, 32, seed=4)
+            assert g.read_accum()[0].tobytes() == want.tobytes(), mode
+    finally:
+        g.set_option(ptcore.OPT_RENDER_MODE, 1)
+        g.close()
