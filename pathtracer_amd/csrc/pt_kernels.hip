@@ -431,11 +431,10 @@ __global__ __launch_bounds__(kTraceBlock) void k_extend(DevScene S, PathState P,
 // With one ray per lane and no refill, a wave lives as long as its longest ray (60-100 loop
 // iterations for a mean of ~10), so most lanes idle.  Here every lane owns a small traversal state
 // machine; when at least kRefillLanes lanes of the wave are idle they take the next rays from the
-// queue with one wave-aggregated atomic.  Each outer iteration runs an "internal" phase (lanes at
-// internal nodes step until at most a quarter of the wave is still descending) and a "leaf" phase
-// (lanes at leaves test their primitives, then pop).  A lane only ever waits — its own sequence of
-// node visits, primitive tests and ray.distance updates is exactly the one of traverse<>, so the
-// results are identical.
+// queue with one wave-aggregated atomic.  Between refills the wave takes traversal steps, each of
+// the kind more of its lanes wait for: an internal-node step or one leaf primitive (wave_step).
+// A lane only ever waits — its own sequence of node visits, primitive tests and ray.distance
+// updates is exactly the one of traverse<>, so the results are identical.
 struct LaneTrav {
     V3 o, d, rcp;
     float dist;
@@ -466,9 +465,6 @@ __device__ __forceinline__ bool lane_pop(LaneTrav& T, const LaneStack& stk) {
 #ifndef PT_SHADE_LANES
 #define PT_SHADE_LANES 16
 #endif
-#ifndef PT_INTERNAL_EXIT_DEN
-#define PT_INTERNAL_EXIT_DEN 4
-#endif
 constexpr int kRefillLanes = PT_REFILL_LANES;  // refill when at least this many lanes of the wave are idle
 constexpr int kFetchChunk = 256;               // rays a wave reserves per atomic on the queue cursor
 constexpr int kShadeLanes = PT_SHADE_LANES;    // fused kernels: shade when at least this many lanes wait for it
@@ -485,8 +481,7 @@ constexpr int kShadeLanes = PT_SHADE_LANES;    // fused kernels: shade when at l
 #define PT_PATH_SHADE_LANES 20
 #endif
 constexpr int kPathRefillLanes = PT_PATH_REFILL_LANES, kPathShadeLanes = PT_PATH_SHADE_LANES;  // k_path's own thresholds (swept on C3)
-constexpr int kStepBiasNum = PT_STEP_BIAS_NUM, kStepBiasDen = PT_STEP_BIAS_DEN;  // k_path: internal step when n_int * NUM >= n_leaf * DEN
-constexpr int kInternalExitDen = PT_INTERNAL_EXIT_DEN;  // leave the internal phase when at most 1/DEN of the traversing lanes still descend
+constexpr int kStepBiasNum = PT_STEP_BIAS_NUM, kStepBiasDen = PT_STEP_BIAS_DEN;  // persistent kernels: internal step when n_int * NUM >= n_leaf * DEN
 
 // load a ray into a lane and do the root test; false = the ray misses the whole scene
 template <bool COUNT>
@@ -610,31 +605,18 @@ __device__ __forceinline__ void step_prim(const DevScene& S, LaneTrav& T, bool& 
     if (done && !lane_pop(T, stk)) active = false;
 }
 
-// internal phase: lanes at internal nodes step until at most 1/kInternalExitDen of the traversing lanes still descend
-template <bool COUNT>
-__device__ __forceinline__ void phase_internal(const DevScene& S, LaneTrav& T, bool& active, const LaneStack& stk, int n_act, uint32_t& nn,
-                                               uint32_t& mine) {
-    while (true) {
-        const bool at_internal = active && !(T.cur & kLeafBit);
-        const unsigned long long m = __ballot(at_internal);
-        if (m == 0 || (__popcll(m) * kInternalExitDen <= n_act && __popcll(m) != n_act)) break;
-        if (at_internal) step_internal<COUNT>(S, T, active, stk, nn, mine);
-    }
-}
-
-// leaf phase: lanes at a leaf test its primitives in index order (last accepted wins), then pop
+// One traversal step of a wave in the persistent kernels: the wave does whichever kind of step
+// (internal node / one leaf primitive) more of its traversing lanes are waiting for.
 template <int PRIM, bool COUNT>
-__device__ __forceinline__ void phase_leaf(const DevScene& S, LaneTrav& T, bool& active, const LaneStack& stk, uint32_t& np) {
-    if (active && (T.cur & kLeafBit)) {
-        uint32_t first = T.cur & kLeafFirstMask;
-        uint32_t count = (T.cur >> kLeafCountShift) & 31u;
-        if (count == 0) {
-            count = S.big_leaf[2 * first + 1];
-            first = S.big_leaf[2 * first];
-        }
-        if (COUNT) np += count;
-        for (uint32_t k = 0; k < count; ++k) test_prim<PRIM>(S, T, first + k);
-        if (!lane_pop(T, stk)) active = false;
+__device__ __forceinline__ void wave_step(const DevScene& S, LaneTrav& T, bool& active, const LaneStack& stk, unsigned long long actv,
+                                          uint32_t& nn, uint32_t& np, uint32_t& mine) {
+    const bool at_internal = active && !(T.cur & kLeafBit);
+    const bool at_leaf = active && !at_internal;
+    const int n_int = __popcll(__ballot(at_internal)), n_leaf = __popcll(actv) - n_int;
+    if (n_int * kStepBiasNum >= n_leaf * kStepBiasDen) {
+        if (at_internal) step_internal<COUNT>(S, T, active, stk, nn, mine);
+    } else {
+        if (at_leaf) step_prim<PRIM, COUNT>(S, T, active, stk, np);
     }
 }
 
@@ -706,12 +688,16 @@ __global__ __launch_bounds__(kTraceBlock) void k_extend_pw(DevScene S, PathState
             if (drained) break;
             continue;
         }
-        phase_internal<COUNT>(S, T, active, stk, __popcll(act), nn, mine);
-        phase_leaf<PRIM, COUNT>(S, T, active, stk, np);
-        // lanes whose stack ran empty in this iteration are done: store the hit record (once)
-        if (!active && ((act >> lane) & 1ull)) {
-            lane_store_hit(P, T);
-            if (COUNT) worst = mine > worst ? mine : worst;
+        // traversal steps (inner hot loop) until enough lanes are free for a refill
+        while (true) {
+            const unsigned long long actv = __ballot(active);
+            if (actv == 0 || (!drained && 64 - __popcll(actv) >= kRefillLanes)) break;
+            wave_step<PRIM, COUNT>(S, T, active, stk, actv, nn, np, mine);
+            // lanes whose stack ran empty in this step are done: store the hit record (once)
+            if (!active && ((actv >> lane) & 1ull)) {
+                lane_store_hit(P, T);
+                if (COUNT) worst = mine > worst ? mine : worst;
+            }
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(counters + CNT_RAYS_CLOSEST, (unsigned long long)n);
@@ -1130,12 +1116,18 @@ __global__ __launch_bounds__(kTraceBlock) void k_tail_pw(DevScene S, PathState P
             if (drained) break;
             continue;  // fewer than kRefillLanes idle cannot be: everyone is idle here
         }
-        phase_internal<COUNT>(S, T, active, stk, __popcll(act), nn, mine);
-        phase_leaf<PRIM, COUNT>(S, T, active, stk, np);
-        if (!active && ((act >> lane) & 1ull)) {
-            lane_store_hit(P, T);
-            pending = true;
-            if (COUNT) worst = mine > worst ? mine : worst;
+        // traversal steps (inner hot loop) until enough lanes wait for shading or are free for a refill
+        while (true) {
+            const unsigned long long actv = __ballot(active);
+            if (actv == 0) break;
+            const int n_wait = __popcll(__ballot(pending));
+            if (n_wait >= kShadeLanes || (!drained && 64 - __popcll(actv) - n_wait >= kRefillLanes)) break;
+            wave_step<PRIM, COUNT>(S, T, active, stk, actv, nn, np, mine);
+            if (!active && ((actv >> lane) & 1ull)) {
+                lane_store_hit(P, T);
+                pending = true;
+                if (COUNT) worst = mine > worst ? mine : worst;
+            }
         }
     }
     wave_add(counters + CNT_RAYS_CLOSEST, rays);
