@@ -156,6 +156,9 @@ def main():
     # ---- warmup + timed region
     g.reset_accum()
     run_steps(0, args.warmup, 0)
+    if use_dist:
+        # warm the collective too (communicator channels and buffers for this message size are set up on first use)
+        dist.reduce(torch.zeros(H, W, 3, dtype=torch.float32, device=f"cuda:{device}"), dst=0, op=dist.ReduceOp.SUM)
     g.reset_counters()
     barrier()
     t0 = time.perf_counter()
