@@ -190,7 +190,7 @@ int pt_sample_skybox(pt_ctx *ctx, const float *dirs, uint64_t n, float *rgb);
 
 /* Scheduling knobs of pt_render (no counterpart in the reference; none of them changes a result):
  *  PT_OPT_BATCH_PATHS     paths per batch, whole samples (0 = default: 512 Mi in mode 1, 8 Mi in mode 0)
- *  PT_OPT_LANES           batches in flight at once, 1..8 (default 8)
+ *  PT_OPT_LANES           batches in flight at once, 1..8 (0 = default: 2 in mode 1, 8 in mode 0)
  *  PT_OPT_TAIL_MIN_PATHS  a batch is handed to the fused tail kernel when at most this many paths
  *  PT_OPT_TAIL_FRACTION   ... or at most batch/fraction paths are still alive (0 = never)
  *  PT_OPT_TAIL_STREAMS    streams the tail kernels are spread over, 1..4 (default 4)

@@ -99,7 +99,7 @@ struct pt_ctx {
     DevBuf d_counters;
     double extend_ms = 0, render_ms = 0, tail_ms = 0;
     uint64_t extend_launches = 0, tail_launches = 0;
-    uint64_t opt_batch_slots = 0 /* 0 = the mode's default */, opt_tail_min = kTailMinPaths, opt_tail_fraction = kTailFraction, opt_lanes = kMaxLanes, opt_tail_streams = 4, opt_tail_paths_per_lane = 4, opt_first_check = 3, opt_simple_extend = 0, opt_bulk_streams = kMaxLanes, opt_tail_mode = 0, opt_render_mode = 1;
+    uint64_t opt_batch_slots = 0 /* 0 = the mode's default */, opt_tail_min = kTailMinPaths, opt_tail_fraction = kTailFraction, opt_lanes = 0 /* 0 = the mode's default */, opt_tail_streams = 4, opt_tail_paths_per_lane = 4, opt_first_check = 3, opt_simple_extend = 0, opt_bulk_streams = kMaxLanes, opt_tail_mode = 0, opt_render_mode = 1;
     std::vector<uint32_t> round_sizes;  // queue length of every round of the last finished batch
 
     int fail(int code, const std::string& msg) {
@@ -785,7 +785,10 @@ int pt_render(pt_ctx* c, uint32_t spp, uint32_t max_depth, uint64_t seed, const 
     if (per_batch * M.npix_pad >= kMaxSlots) return c->fail(PT_ERR_LIMIT, "pt_render: batch too large");
     const uint64_t batch_slots = per_batch * M.npix_pad;
     const uint32_t n_batches = (uint32_t)((spp + per_batch - 1) / per_batch);
-    const uint32_t n_lanes = (uint32_t)std::min<uint64_t>(c->opt_lanes, n_batches);
+    // path-kernel mode: two launches in flight cover each other's ends (more measured no faster) and bound the
+    // radiance slabs to 2 x 8 GB; the wavefront rounds need all eight
+    const uint64_t want_lanes = c->opt_lanes ? c->opt_lanes : (c->opt_render_mode == 1 ? 2 : kMaxLanes);
+    const uint32_t n_lanes = (uint32_t)std::min<uint64_t>(want_lanes, n_batches);
     J.max_depth = max_depth;
     J.rounds = max_depth == 0 ? 0 : 2 * max_depth;  // each iteration traces at most twice
     J.k0 = (uint32_t)seed;
@@ -1009,7 +1012,7 @@ int pt_set_option(pt_ctx* c, int option, uint64_t value) {
     if (!c) return PT_ERR_INVALID;
     switch (option) {
         case PT_OPT_BATCH_PATHS: c->opt_batch_slots = value ? std::max<uint64_t>(value, 64) : 0; return PT_OK;
-        case PT_OPT_LANES: c->opt_lanes = std::min<uint64_t>(std::max<uint64_t>(value, 1), kMaxLanes); return PT_OK;
+        case PT_OPT_LANES: c->opt_lanes = std::min<uint64_t>(value, kMaxLanes); return PT_OK;
         case PT_OPT_TAIL_MIN_PATHS: c->opt_tail_min = value; return PT_OK;
         case PT_OPT_TAIL_FRACTION: c->opt_tail_fraction = value; return PT_OK;
         case PT_OPT_TAIL_STREAMS: c->opt_tail_streams = std::min<uint64_t>(std::max<uint64_t>(value, 1), 4); return PT_OK;

@@ -355,7 +355,7 @@ def test_scheduling_does_not_change_results(ptcore, pairs, name):
         dict(batch=2 * W * H, lanes=3, tail_min=0, tail_frac=0, mode=1),            # k_path: one persistent kernel, state in registers
         dict(batch=1 << 23, lanes=2, tail_min=0, tail_frac=0, mode=1),
         dict(batch=1 << 23, lanes=1, tail_min=65536, tail_frac=16),    # wavefront defaults
-        dict(batch=0, lanes=8, tail_min=65536, tail_frac=16, mode=1),  # defaults
+        dict(batch=0, lanes=0, tail_min=65536, tail_frac=16, mode=1),  # defaults
     ]
     try:
         for cfg in configs:
@@ -376,7 +376,7 @@ def test_scheduling_does_not_change_results(ptcore, pairs, name):
             assert rays == orays, cfg
     finally:
         g.set_option(ptcore.OPT_BATCH_PATHS, 0)
-        g.set_option(ptcore.OPT_LANES, 8)
+        g.set_option(ptcore.OPT_LANES, 0)
         g.set_option(ptcore.OPT_TAIL_MIN_PATHS, 65536)
         g.set_option(ptcore.OPT_TAIL_FRACTION, 16)
         g.set_option(ptcore.OPT_SIMPLE_EXTEND, 0)
