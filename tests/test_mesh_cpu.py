@@ -34,7 +34,17 @@ def _python_loader(path):
     return np.concatenate([pos, nrm, mats[mat_id]], axis=1).astype(np.float32)
 
 
+def _need_render():
+    """The CLI is a build product (pathtracer_amd/csrc/Makefile, __graft_entry__.build()); build it if it is missing."""
+    if not os.path.exists(RENDER):
+        subprocess.run(["make", "-C", os.path.join(os.path.dirname(HERE), "pathtracer_amd", "csrc"), "../host/render"],
+                       capture_output=True, text=True)
+    if not os.path.exists(RENDER):
+        pytest.fail("pathtracer_amd/host/render is not built: run __graft_entry__.build()")
+
+
 def _cpp_loader(path, tmp_path):
+    _need_render()
     out = str(tmp_path / "mesh.bin")
     r = subprocess.run([RENDER, "--obj", path, "--dump-mesh", out], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
@@ -84,6 +94,7 @@ def test_generated_mesh_round_trip(tmp_path):
 
 
 def test_missing_normals_and_files_are_errors(tmp_path):
+    _need_render()
     bad = os.path.join(FIX, "no_normals.obj")
     with pytest.raises(ValueError):
         mesh.load_mesh(bad, BACKUP)
