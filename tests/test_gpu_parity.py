@@ -354,6 +354,7 @@ def test_scheduling_does_not_change_results(ptcore, pairs, name):
         dict(batch=2 * W * H, lanes=3, tail_min=1 << 30, tail_frac=1, first=0),     # tail kernel does everything from the queue
         dict(batch=2 * W * H, lanes=3, tail_min=0, tail_frac=0, mode=1),            # k_path: one persistent kernel, state in registers
         dict(batch=1 << 23, lanes=2, tail_min=0, tail_frac=0, mode=1),
+        dict(batch=W * H, lanes=2, tail_min=0, tail_frac=0, mode=1),              # six batches through two lanes
         dict(batch=1 << 23, lanes=1, tail_min=65536, tail_frac=16),    # wavefront defaults
         dict(batch=0, lanes=0, tail_min=65536, tail_frac=16, mode=1),  # defaults
     ]
