@@ -1,0 +1,93 @@
+"""Randomised parity campaign, GPU (through the C ABI) against the CPU oracle, bit for bit:
+   python3 tools/soak.py [minutes] [first_seed]
+Every round draws a scene (soup / statue / spheres of random size and materials, sometimes with a
+specular floor or a speculaty > 1 material so that shadow rays run), a camera, an image size, a
+depth and a sample count, and compares BVH, 20 000 traces (closest and any), camera state, and
+the frame sums in both pt_render modes.  Stops at the first difference (exit code 1)."""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, '.')
+import torch  # noqa: F401,E402
+from oracle import orc  # noqa: E402
+from pathtracer_amd import ptcore, scenes  # noqa: E402
+
+
+def draw_scene(rng):
+    kind = rng.integers(0, 5)
+    if kind == 0:
+        n = int(rng.integers(50, 60000))
+        pos, nrm, mat, mats = scenes.soup_scene(n, int(rng.integers(1, 1 << 30)), floor_speculaty=float(rng.choice([0.0, 0.5, 1.0])))
+        if rng.random() < 0.3:
+            mats = mats.copy()
+            mats["a"][rng.integers(0, 64)] = 1.5  # speculaty > 1: the NEE weight becomes non-zero (quirk Q2)
+        return "soup%d" % n, (pos, nrm, mat, mats)
+    if kind == 1:
+        nu, nv = int(rng.integers(8, 160)), int(rng.integers(6, 90))
+        glass = scenes.GLASS_BLUE if rng.random() < 0.5 else scenes.GLASS_GREEN
+        return "statue%dx%d" % (nu, nv), scenes.statue_scene(nu, nv, int(rng.integers(4, 64)), int(rng.integers(1, 1000)), glass, float(rng.choice([0.0, 0.5])))
+    if kind == 4:  # large overlapping triangles: deep trees, long stacks (beyond the LDS levels), many coincident boxes
+        n = int(rng.integers(200, 5000))
+        ctr = rng.uniform(-1, 1, size=(n, 3)) * [1, 0.3, 1] + [0.7, 0.1, 0.6]
+        a, b = rng.normal(size=(n, 3)) * rng.uniform(0.2, 1.5), rng.normal(size=(n, 3)) * rng.uniform(0.2, 1.5)
+        pos = np.concatenate([ctr, ctr + a, ctr + b], axis=1).astype(np.float32)
+        if rng.random() < 0.5:
+            pos[: n // 10] = pos[0]  # a stack of identical triangles -> a leaf with many primitives
+        rows = [scenes.GLASS_BLUE, scenes.diffuse(float(rng.choice([0.0, 0.3, 1.2])), (0.7, 0.6, 0.5))]
+        return "overlap%d" % n, scenes.wrap_mesh(pos, scenes._flat_normals(pos), rng.integers(0, 2, n).astype(np.uint32), rows)
+    if kind == 2:
+        return "cube", scenes.glass_cube_scene(floor_speculaty=float(rng.choice([0.0, 0.5])), lift=float(rng.choice([0.0, 0.2])))
+    return "spheres", scenes.default_scene()
+
+
+def main():
+    minutes = float(sys.argv[1]) if len(sys.argv) > 1 else 3.0
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    sky = scenes.make_sky()
+    t_end = time.time() + 60 * minutes
+    rounds = 0
+    while time.time() < t_end:
+        seed = seed0 + rounds
+        rng = np.random.default_rng(seed)
+        name, scene = draw_scene(rng)
+        g = ptcore.PathTracer(0).set_scene(scene, sky)
+        o = orc.from_scene(scene, sky)
+        what = "bvh"
+        ok = all(a.tobytes() == b.tobytes() for a, b in zip(g.bvh()[:2], o.bvh()[:2]))
+        if ok:
+            what = "trace"
+            rays = scenes.random_rays(20000, seed=seed)
+            for any_hit in (False, True):
+                a, b = g.trace(rays, any_hit), o.trace(rays, any_hit)
+                ok = ok and a.tobytes() == b.tobytes()
+        if ok:
+            what = "render"
+            spheres = name == "spheres"
+            co = scenes.SPHERE_CAMERA_ORIGIN if spheres else scenes.CAMERA_ORIGIN
+            ct = scenes.SPHERE_CAMERA_TARGET if spheres else scenes.CAMERA_TARGET
+            co = tuple(np.float32(co) + rng.normal(scale=0.3, size=3).astype(np.float32))
+            W, H = int(rng.integers(1, 200)), int(rng.integers(1, 120))
+            depth, spp = int(rng.choice([0, 1, 2, 5, 32])), int(rng.integers(1, 5))
+            o.set_camera(co, ct, W, H)
+            o.render(spp, depth, seed=seed, nthreads=8, nee_mode=1)
+            want = o.read_accum()[0]
+            for mode in (1, 0):
+                g.set_option(ptcore.OPT_RENDER_MODE, mode)
+                g.set_camera(co, ct, W, H)
+                g.render(spp, depth, seed=seed)
+                ok = ok and g.read_accum()[0].tobytes() == want.tobytes()
+            ok = ok and g.read_rgb8().tobytes() == o.read_rgb8().tobytes()
+            what += " %dx%d depth %d spp %d" % (W, H, depth, spp)
+        g.close()
+        o.close()
+        rounds += 1
+        print(("ok   " if ok else "DIFF ") + "seed %d %s %s" % (seed, name, what), flush=True)
+        if not ok:
+            sys.exit(1)
+    print("soak: %d rounds, no difference" % rounds)
+
+
+if __name__ == "__main__":
+    main()
