@@ -1,5 +1,5 @@
 """Randomised parity campaign, GPU (through the C ABI) against the CPU oracle, bit for bit:
-   python3 tools/soak.py [minutes] [first_seed]
+   python3 tests/soak.py [minutes] [first_seed]
 Every round draws a scene (soup / statue / spheres of random size and materials, sometimes with a
 specular floor or a speculaty > 1 material so that shadow rays run), a camera, an image size, a
 depth and a sample count, and compares BVH, 20 000 traces (closest and any), camera state, and
