@@ -1,5 +1,5 @@
 """Randomised parity campaign, GPU (through the C ABI) against the CPU oracle, bit for bit:
-   python3 tests/soak.py [minutes] [first_seed]
+   python3 tests/soak.py [minutes] [first_seed] [image_scale]
 Every round draws a scene (soup / statue / spheres of random size and materials, sometimes with a
 specular floor or a speculaty > 1 material so that shadow rays run), a camera, an image size, a
 depth and a sample count, and compares BVH, 20 000 traces (closest and any), camera state, and
@@ -13,6 +13,9 @@ sys.path.insert(0, '.')
 import torch  # noqa: F401,E402
 from oracle import orc  # noqa: E402
 from pathtracer_amd import ptcore, scenes  # noqa: E402
+
+
+SCALE = 1  # image size scale (third argument)
 
 
 def draw_scene(rng):
@@ -45,6 +48,8 @@ def draw_scene(rng):
 def main():
     minutes = float(sys.argv[1]) if len(sys.argv) > 1 else 3.0
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    global SCALE
+    SCALE = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     sky = scenes.make_sky()
     t_end = time.time() + 60 * minutes
     rounds = 0
@@ -68,7 +73,7 @@ def main():
             co = scenes.SPHERE_CAMERA_ORIGIN if spheres else scenes.CAMERA_ORIGIN
             ct = scenes.SPHERE_CAMERA_TARGET if spheres else scenes.CAMERA_TARGET
             co = tuple(np.float32(co) + rng.normal(scale=0.3, size=3).astype(np.float32))
-            W, H = int(rng.integers(1, 200)), int(rng.integers(1, 120))
+            W, H = int(rng.integers(1, 200 * SCALE)), int(rng.integers(1, 120 * SCALE))
             depth, spp = int(rng.choice([0, 1, 2, 5, 32])), int(rng.integers(1, 5))
             o.set_camera(co, ct, W, H)
             o.render(spp, depth, seed=seed, nthreads=8, nee_mode=1)
