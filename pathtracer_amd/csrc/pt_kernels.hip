@@ -472,13 +472,13 @@ constexpr int kShadeLanes = PT_SHADE_LANES;    // fused kernels: shade when at l
 #define PT_STEP_BIAS_NUM 1
 #endif
 #ifndef PT_STEP_BIAS_DEN
-#define PT_STEP_BIAS_DEN 1
+#define PT_STEP_BIAS_DEN 2
 #endif
 #ifndef PT_PATH_REFILL_LANES
 #define PT_PATH_REFILL_LANES 8
 #endif
 #ifndef PT_PATH_SHADE_LANES
-#define PT_PATH_SHADE_LANES 20
+#define PT_PATH_SHADE_LANES 24
 #endif
 constexpr int kPathRefillLanes = PT_PATH_REFILL_LANES, kPathShadeLanes = PT_PATH_SHADE_LANES;  // k_path's own thresholds (swept on C3)
 #ifndef PT_INT_REPEAT
