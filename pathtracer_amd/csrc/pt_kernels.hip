@@ -45,17 +45,20 @@ __device__ __forceinline__ V3 ld3(const float* p) { return V3{p[0], p[1], p[2]};
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 struct LaneStack {
     lds_u64* lds;         // &smem[threadIdx.x], kept in the LDS address space so accesses are ds_read/ds_write_b64
-    unsigned long long* spill;  // &spill[global thread id]
+    unsigned long long* spill;  // the launch's spill area (wave-uniform; a lane's entries are at [level][global thread id])
     uint32_t spill_stride;
+    __device__ __forceinline__ unsigned long long* spill_at(uint32_t level) const {
+        return spill + ((size_t)(level - kLdsStack) * spill_stride + (blockIdx.x * blockDim.x + threadIdx.x));
+    }
     __device__ __forceinline__ void put(uint32_t level, uint32_t ref, float tmin) const {
         const unsigned long long e = (unsigned long long)ref | ((unsigned long long)__float_as_uint(tmin) << 32);
         if (level < (uint32_t)kLdsStack) lds[level * kTraceBlock] = e;
-        else spill[(size_t)(level - kLdsStack) * spill_stride] = e;
+        else *spill_at(level) = e;
     }
     __device__ __forceinline__ void get(uint32_t level, uint32_t* ref, float* tmin) const {
         unsigned long long e;
         if (level < (uint32_t)kLdsStack) e = lds[level * kTraceBlock];
-        else e = spill[(size_t)(level - kLdsStack) * spill_stride];
+        else e = *spill_at(level);
         *ref = (uint32_t)e;
         *tmin = __uint_as_float((uint32_t)(e >> 32));
     }
@@ -162,7 +165,7 @@ __device__ __forceinline__ void traverse(const DevScene& S, V3 o, V3 d, float& d
 __device__ __forceinline__ LaneStack make_stack(unsigned long long* smem, const LaunchCfg& cfg) {
     LaneStack s;
     s.lds = (lds_u64*)smem + threadIdx.x;
-    s.spill = cfg.spill + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    s.spill = cfg.spill;
     s.spill_stride = cfg.spill_stride;
     return s;
 }
@@ -1169,7 +1172,8 @@ __global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, c
     const DevCamera cam = *camp;
     const uint32_t n = n_samples * M.npix_pad;
     const uint32_t lane = threadIdx.x & 63u;
-    uint32_t nn = 0, np = 0, worst = 0, mine = 0, rays = 0, paths = 0;
+    uint32_t nn = 0, np = 0, worst = 0, mine = 0;
+    uint32_t rays = 0, paths = 0;  // wave-uniform tallies (scalar registers)
     LaneTrav T;
     T.cur = 0; T.sp = 0; T.dist = 0.f; T.hslot = PT_MISS; T.hinside = 0; T.hu = T.hv = 0.f; T.slot = 0;
     T.o = T.d = T.rcp = V3{0.f, 0.f, 0.f};
@@ -1191,6 +1195,7 @@ __global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, c
         // for latency (shade at once, both kinds of traversal step every turn), not for full waves
         if (pend != 0 && (__popcll(pend) >= kPathShadeLanes || act == 0 || drained)) {
             const unsigned long long t0 = st.now();
+            bool traced = false;
             if (pending) {
                 pending = false;
                 HitVals hv;
@@ -1202,13 +1207,14 @@ __global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, c
                 pv.d = T.d;
                 V3 radiance;
                 if (shade_core<PRIM, NEE>(S, pv, hv, depth, k0, k1, stk, counters, radiance)) {
-                    rays += 1;
+                    traced = true;
                     active = lane_start_ray<COUNT>(S, T, make_float4(pv.o.x, pv.o.y, pv.o.z, pv.tmax), make_float4(pv.d.x, pv.d.y, pv.d.z, 0.f), nn, mine);
                     pending = !active;  // a ray that misses the root box is shaded as a miss
                 } else {
                     out[T.slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
                 }
             }
+            rays += (uint32_t)__popcll(__ballot(traced));
             st.add(0, pend, t0);
             continue;
         }
@@ -1217,6 +1223,7 @@ __global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, c
         if (!drained && n_idle >= kPathRefillLanes) {
             const unsigned long long t0 = st.now();
             if (!wave_fetch_chunk(cursor, n, chunk, chunk_next, chunk_end)) drained = true;
+            bool made = false;
             if (!active && !pending && !drained) {
                 const uint32_t idx = chunk_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                 if (idx < chunk_end) {
@@ -1235,11 +1242,10 @@ __global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, c
                         pv.acc = V3{0.f, 0.f, 0.f};
                         pv.pixel = y * M.width + x;
                         pv.sample = sample;
-                        paths += 1;
+                        made = true;
                         if (depth == 0) {  // `for _ in 0..0`: the sample is (0,0,0) and nothing is traced
                             out[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
                         } else {
-                            rays += 1;
                             active = lane_start_ray<COUNT>(S, T, make_float4(o.x, o.y, o.z, kInf), make_float4(d.x, d.y, d.z, 0.f), nn, mine);
                             pending = !active;
                         }
@@ -1247,6 +1253,9 @@ __global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, c
                 }
             }
             chunk_next = chunk_next + (uint32_t)n_idle < chunk_end ? chunk_next + (uint32_t)n_idle : chunk_end;
+            const uint32_t n_made = (uint32_t)__popcll(__ballot(made));
+            paths += n_made;
+            if (depth != 0) rays += n_made;
             st.add(1, idle, t0);
             continue;
         }
@@ -1307,9 +1316,11 @@ __global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, c
 #endif
     st.add(5, ~0ull, t_begin);  // wave lifetime
     st.flush(counters);
-    wave_add(counters + CNT_PATHS, paths);
-    wave_add(counters + CNT_RAYS_CLOSEST, rays);
-    wave_add(counters + CNT_TAIL_RAYS, rays);
+    if (lane == 0) {
+        atomicAdd(counters + CNT_PATHS, (unsigned long long)paths);
+        atomicAdd(counters + CNT_RAYS_CLOSEST, (unsigned long long)rays);
+        atomicAdd(counters + CNT_TAIL_RAYS, (unsigned long long)rays);
+    }
     if (COUNT) {
         wave_add(counters + CNT_TAIL_NODE_TESTS, nn);
         wave_add(counters + CNT_TAIL_PRIM_TESTS, np);
