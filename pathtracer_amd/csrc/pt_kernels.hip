@@ -1205,6 +1205,13 @@ __global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, c
                 hv.v = T.hv;
                 pv.o = T.o;
                 pv.d = T.d;
+                {   // the RNG counter words (pixel, sample) follow from the slot: not kept across the traversal loop
+                    const uint32_t pix_idx = T.slot / n_samples;
+                    uint32_t x, y;
+                    map_pixel(M, pix_idx, &x, &y);
+                    pv.pixel = y * M.width + x;
+                    pv.sample = sample_base + (T.slot - pix_idx * n_samples);
+                }
                 V3 radiance;
                 if (shade_core<PRIM, NEE>(S, pv, hv, depth, k0, k1, stk, counters, radiance)) {
                     traced = true;
@@ -1240,8 +1247,6 @@ __global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, c
                         pv.flags = 0;
                         pv.cos_i = 0.f;
                         pv.acc = V3{0.f, 0.f, 0.f};
-                        pv.pixel = y * M.width + x;
-                        pv.sample = sample;
                         made = true;
                         if (depth == 0) {  // `for _ in 0..0`: the sample is (0,0,0) and nothing is traced
                             out[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
