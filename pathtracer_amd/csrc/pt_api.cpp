@@ -582,7 +582,7 @@ static int lane_alloc(pt_ctx* c, RenderLane& L, uint64_t slots, uint32_t rounds)
     if (c->opt_render_mode != 1 && c->nee && L.d_acc.bytes < slots * 16)
         if ((rc = dev_alloc(c, L.d_acc, slots * 16))) return rc;
     if (rounds + 2 > L.qn_len) {  // queue lengths [0, rounds+2) then one fetch cursor per round
-        if ((rc = dev_alloc(c, L.d_qn, (size_t)(rounds + 2) * 8))) return rc;
+        if ((rc = dev_alloc(c, L.d_qn, (size_t)(rounds + 2) * 8 + 64))) return rc;  // + 8 region cursors of k_path
         L.qn_len = rounds + 2;
     }
     if (!L.d_spill.p || L.d_spill.bytes < c->spill_bytes)
@@ -644,7 +644,7 @@ static int lane_start(pt_ctx* c, RenderLane& L, const RenderJob& J, uint32_t bat
     L.sample_base = sample_base;
     L.round = 0;
     L.state = RenderLane::RUNNING;
-    PT_HIP(c, hipMemsetAsync(qn, 0, (size_t)(J.rounds + 2) * 8, L.stream));
+    PT_HIP(c, hipMemsetAsync(qn, 0, (size_t)(J.rounds + 2) * 8 + 64, L.stream));
     if (c->opt_render_mode == 1) {
         // the whole batch in one persistent kernel (generate + sample, state in registers)
         hipEvent_t a = nullptr, b = nullptr;
@@ -654,7 +654,7 @@ static int lane_start(pt_ctx* c, RenderLane& L, const RenderJob& J, uint32_t bat
             PT_HIP(c, hipEventRecord(a, L.stream));
         }
         launch_path(c->prim_kind, c->nee, J.count, c->ds, (const DevCamera*)c->d_cam.p, J.M, ns, sample_base, J.max_depth, J.k0, J.k1,
-                    L.ps.out, qn, L.cfg, (unsigned long long*)c->d_counters.p, L.stream);
+                    L.ps.out, qn + 2 * (J.rounds + 2), L.cfg, (unsigned long long*)c->d_counters.p, L.stream);
         if (J.timed) {
             PT_HIP(c, hipEventRecord(b, L.stream));
             c->tail_events.push_back(a);

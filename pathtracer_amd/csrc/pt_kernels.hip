@@ -655,6 +655,34 @@ __device__ __forceinline__ bool wave_fetch_chunk(uint32_t* cursor, uint32_t n, u
     return true;
 }
 
+// XCD-aware variant for k_path: the slot range is cut into 8 * strips strips; strip s belongs to the
+// region of XCD s % 8.  A wave draws chunks from the region of the XCD it runs on, so that an XCD's own
+// L2 sees one part of the scene (C3: 11.0 -> 11.4 Grays/s), and moves on to the next region when
+// its own is used up.  cursor[0..7] count the chunks handed out per region.
+__device__ __forceinline__ bool wave_fetch_chunk_xcd(uint32_t* cursor, uint32_t n, uint32_t chunk, uint32_t strips, uint32_t& region, uint32_t& tried,
+                                                     uint32_t& chunk_next, uint32_t& chunk_end) {
+    if (chunk_next < chunk_end) return true;
+    const uint32_t n_chunks = (n + chunk - 1u) / chunk;
+    const uint32_t per_strip = (n_chunks + 8u * strips - 1u) / (8u * strips);  // chunks per strip
+    while (tried < 8u) {
+        uint32_t c = 0;
+        if ((threadIdx.x & 63u) == 0) c = atomicAdd(cursor + region, 1u);
+        c = __builtin_amdgcn_readfirstlane(__shfl(c, 0, 64));
+        const uint32_t strip = (c / per_strip) * 8u + region;   // the region's strips are 8 apart
+        const uint32_t g = strip * per_strip + c % per_strip;   // global chunk index
+        if (c < per_strip * strips && g < n_chunks) {
+            chunk_next = g * chunk;
+            chunk_end = chunk_next + chunk < n ? chunk_next + chunk : n;
+            return true;
+        }
+        // g grows with c, so this region is used up: go on with the next one
+        region = (region + 1u) & 7u;
+        tried += 1u;
+    }
+    chunk_next = chunk_end = 0;
+    return false;
+}
+
 __device__ __forceinline__ void reduce_worst(unsigned long long* counters, uint32_t worst) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -1183,6 +1211,11 @@ __global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, c
     pv.flags = pv.pixel = pv.sample = 0;
     bool active = false, pending = false, drained = false;
     uint32_t chunk_next = 0, chunk_end = 0;
+    // wave-uniform: the XCD this wave runs on (HW_REG_XCC_ID[3:0]) picks its region of the slot range
+    uint32_t region = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 7u, tried = 0;
+    // one band of the image per XCD keeps the most locality (256 spp: +3 %); with few samples per pixel the bands
+    // are too uneven, so each XCD then gets 8 strips spread over the image (64 spp: +1 % instead of -3 %)
+    const uint32_t xcd_strips = n_samples >= 128u ? 1u : 8u;
     PhaseStats st;
     st.init();
     const unsigned long long t_begin = st.now();
@@ -1229,7 +1262,7 @@ __global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, c
         const int n_idle = __popcll(idle);
         if (!drained && n_idle >= kPathRefillLanes) {
             const unsigned long long t0 = st.now();
-            if (!wave_fetch_chunk(cursor, n, chunk, chunk_next, chunk_end)) drained = true;
+            if (!wave_fetch_chunk_xcd(cursor, n, chunk, xcd_strips, region, tried, chunk_next, chunk_end)) drained = true;
             bool made = false;
             if (!active && !pending && !drained) {
                 const uint32_t idx = chunk_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
