@@ -469,7 +469,10 @@ __device__ __forceinline__ bool lane_pop(LaneTrav& T, const LaneStack& stk) {
 #define PT_SHADE_LANES 16
 #endif
 constexpr int kRefillLanes = PT_REFILL_LANES;  // refill when at least this many lanes of the wave are idle
-constexpr int kFetchChunk = 256;               // rays a wave reserves per atomic on the queue cursor
+#ifndef PT_FETCH_CHUNK
+#define PT_FETCH_CHUNK 256
+#endif
+constexpr int kFetchChunk = PT_FETCH_CHUNK;               // rays a wave reserves per atomic on the queue cursor
 constexpr int kShadeLanes = PT_SHADE_LANES;    // fused kernels: shade when at least this many lanes wait for it
 #ifndef PT_STEP_BIAS_NUM
 #define PT_STEP_BIAS_NUM 1
