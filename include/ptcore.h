@@ -101,11 +101,15 @@ typedef struct pt_counters {
     uint64_t node_tests;     /* AABB records tested: 1 (root) + 2 per internal node entered (PT_RENDER_COUNT) */
     uint64_t prim_tests;     /* Primitive::intersect calls (PT_RENDER_COUNT) */
     uint64_t extend_launches;
-    double extend_ms;        /* sum of HIP-event durations of the round traversal kernel (PT_RENDER_TIMED) */
-    double render_ms;        /* HIP-event duration of all pt_render calls since reset */
+    double extend_ms;        /* PT_RENDER_TIMED: time during which at least one round traversal kernel (k_extend) was running,
+                                from HIP events on the launching streams (union of the launch intervals) */
+    double render_ms;        /* host wall-clock from submission to completion of every render call since reset, summed */
     /* the part of the above done by the fused tail kernel (paths finished outside the rounds) */
     uint64_t tail_rays, tail_node_tests, tail_prim_tests, tail_launches;
-    double tail_ms;
+    double tail_ms;          /* as extend_ms, for k_path (render mode 1) / the fused tail kernel (mode 0) */
+    /* plain sums of the same launch durations (= a profiler's average duration x launches); they exceed
+     * extend_ms / tail_ms exactly when launches overlapped (several batches or calls in flight) */
+    double extend_ms_sum, tail_ms_sum;
 } pt_counters;
 
 /* flags for pt_render */
@@ -164,6 +168,18 @@ int pt_generate(pt_ctx *ctx, const uint32_t *xy, uint64_t n, uint32_t sample, ui
  * src/main.rs:159.  shard may be NULL (= PT_SHARD_ALL, sample_begin = samples rendered so far). */
 int pt_render(pt_ctx *ctx, uint32_t spp, uint32_t max_depth, uint64_t seed, const pt_shard *shard,
               uint32_t flags);
+/* The same call without waiting for the result (no counterpart in the reference, whose loop renders one
+ * sample per frame, src/main.rs:143,159, and would otherwise pay a whole kernel's fill-and-drain per
+ * sample): the call is queued and returns; consecutive calls overlap on the device (the few long paths
+ * that end one call's kernel run beside the start of the next call's) while the accumulator is still
+ * summed in call order and sample order, so the sums are bit-identical to the same sequence of pt_render
+ * calls.  pt_wait blocks until everything queued has been added; every entry point that reads or
+ * changes the frame, camera, scene, options or counters waits first by itself.  Progress is made
+ * inside pt_render_async / pt_wait calls (there is no background thread).  pt_render = pt_render_async
+ * + pt_wait.  An error of a queued call is reported by the call that waits for it. */
+int pt_render_async(pt_ctx *ctx, uint32_t spp, uint32_t max_depth, uint64_t seed, const pt_shard *shard,
+                    uint32_t flags);
+int pt_wait(pt_ctx *ctx);
 /* The pixels a shard owns, in the order the device walks them (device-free; the same mapping
  * function is compiled into the kernels).  xy: up to cap (x, y) pairs; n_out: pixels owned.
  * tile = 8 with nranks = 1 is the PT_SHARD_ALL order. */
@@ -183,6 +199,22 @@ int pt_accum_device_ptr(pt_ctx *ctx, void **ptr, uint64_t *n_floats);
 /* add `spp` to the sample count after an external reduce put other ranks' sums in accum. */
 int pt_add_external_samples(pt_ctx *ctx, float spp);
 
+/* Tile-sharded frames (BASELINE config C4; no counterpart in the reference): the tiles a rank owns as one
+ * compact slab, so that ranks exchange their own pixels only (one RCCL gather of nranks slabs of
+ * W*H*12/nranks bytes instead of a reduce of nranks whole frames).  A slab holds the shard's pixels in the
+ * shard's own order (pt_shard_map order: tile by tile, 8x8 blocks inside a tile), 3 floats each, with the
+ * padding pixels of edge tiles kept as zeros: pt_shard_slab_floats() floats (device-free; ranks differ by at
+ * most one tile, pad to rank 0's size for a gather of equal parts).
+ *  pt_shard_pack    slab <- this context's accumulator (slab_dev: DEVICE memory of >= that many floats)
+ *  pt_shard_unpack  this context's accumulator <- slab, for the pixels of `shard` only (the gathering rank
+ *                   calls it once per received slab with that rank's shard).  Add the other ranks' sample
+ *                   count with pt_add_external_samples only when they rendered samples this rank did not.
+ * Both wait for queued render calls, run on the context's stream and return when the copy is done; the caller
+ * orders them against its own streams (the slab must not be in use by a collective still in flight). */
+int pt_shard_slab_floats(uint32_t width, uint32_t height, uint32_t tile, uint32_t rank, uint32_t nranks, uint64_t *n_floats);
+int pt_shard_pack(pt_ctx *ctx, const pt_shard *shard, float *slab_dev, uint64_t cap_floats);
+int pt_shard_unpack(pt_ctx *ctx, const pt_shard *shard, const float *slab_dev, uint64_t n_floats);
+
 /* BVH::intersect_closest / intersect_any (src/bvh.rs:180-271) over a batch of rays. */
 int pt_trace(pt_ctx *ctx, const pt_ray *rays, uint64_t n, int any_hit, pt_hit *hits);
 /* Scene::sample_skybox (src/scene.rs:162-169) for n directions (n x 3 floats) -> n x 3 floats. */
@@ -190,7 +222,8 @@ int pt_sample_skybox(pt_ctx *ctx, const float *dirs, uint64_t n, float *rgb);
 
 /* Scheduling knobs of pt_render (no counterpart in the reference; none of them changes a result):
  *  PT_OPT_BATCH_PATHS     paths per batch, whole samples (0 = default: 512 Mi in mode 1, 8 Mi in mode 0)
- *  PT_OPT_LANES           batches in flight at once, 1..8 (0 = default: 2 in mode 1, 8 in mode 0)
+ *  PT_OPT_LANES           batches in flight at once, 1..8 (0 = default: mode 1: 2 for large batches up to 8 for
+ *                         small ones (few samples per call); mode 0: 8)
  *  PT_OPT_TAIL_MIN_PATHS  a batch is handed to the fused tail kernel when at most this many paths
  *  PT_OPT_TAIL_FRACTION   ... or at most batch/fraction paths are still alive (0 = never)
  *  PT_OPT_TAIL_STREAMS    streams the tail kernels are spread over, 1..4 (default 4)

@@ -41,7 +41,7 @@ PT_HD float pt_rint_small(float x) { return (x + 12582912.0f) - 12582912.0f; }
 /* sin and cos of x, |x| <= ~8192 (the path only passes phi in [0, 2*pi]). */
 PT_HD void pt_sincosf(float x, float *s_out, float *c_out) {
     float kf = pt_rint_small(x * 0.636619772367581343f); /* 2/pi */
-    float r = x - kf * 1.5625f;
+    float r = x - kf * 1.5703125f; /* pi/2 in three parts (Cody-Waite): 1.5703125 + 4.8375e-4 + 7.5498e-8 */
     r = r - kf * 4.837512969970703125e-4f;
     r = r - kf * 7.54978995489188216e-8f;
     float z = r * r;

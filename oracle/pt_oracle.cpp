@@ -653,8 +653,15 @@ struct orc_ctx {
                 float nee_w = fmin_(1.0f - speculaty, 0.0f);
                 if (!lights.empty() && (nee_mode == 0 || nee_w != 0.0f)) {
                     U4 rn = philox4x32_10(k.k0, k.k1, k.pixel, k.sample, 1 + it, 1);
+                    // bvh.rs:273-284: Range::new(0, light_count).ind_sample() — rand 0.3.15 rejects draws at or above
+                    // the largest multiple of the range (`zone`) and returns low + v % range.  The generator is the
+                    // counter-based stream here, so the draws are its 32-bit words: first word 0 of the NEE block,
+                    // then word 0 of blocks (iteration, stream 2, 3, ...) for as long as a draw is rejected.
                     size_t nl = lights.size();
-                    uint64_t light = lights[rn.v[0] % nl];
+                    uint32_t pick = rn.v[0];
+                    const uint32_t zone = 0xffffffffu - 0xffffffffu % (uint32_t)nl;
+                    for (uint32_t j = 0; pick >= zone; ++j) pick = philox4x32_10(k.k0, k.k1, k.pixel, k.sample, 1 + it, 2 + j).v[0];
+                    uint64_t light = lights[pick % nl];
                     V3 Q = prim_random_point(light, rn);
                     V3 light_dir = normalize(Q - P);
                     Ray god{P + (20.0f * EPS) * light_dir, light_dir, INF};

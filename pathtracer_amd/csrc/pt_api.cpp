@@ -7,7 +7,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
+#include <deque>
 #include <string>
 #include <thread>
 #include <vector>
@@ -41,6 +43,7 @@ constexpr uint64_t kTailMinPaths = 65536;      // hand a batch to the fused tail
 constexpr uint64_t kTailFraction = 16;         // ... or below 1/16 of the batch
 
 // One batch in flight.
+struct RenderJob;
 struct RenderLane {
     enum State { IDLE, RUNNING, TAILING, READY, DRAINING };
     State state = IDLE;
@@ -53,9 +56,35 @@ struct RenderLane {
     uint64_t cap_slots = 0;
     uint32_t qn_len = 0;
     uint32_t batch = 0, ns = 0, sample_base = 0, round = 0, live = 0;
+    RenderJob* job = nullptr;  // the call this batch belongs to
+    uint64_t seq = 0;                 // place of the batch in the context-wide accumulation order
+};
+
+// One pt_render / pt_render_async call: its frame parameters and how far its batches have got.
+struct RenderJob {
+    PixelMap M;
+    uint32_t max_depth, rounds, k0, k1;
+    bool timed, count;
+    uint32_t tail_threshold;
+    uint32_t spp, sample_begin, n_batches, max_lanes;
+    uint64_t per_batch, batch_slots;
+    uint32_t next_batch = 0, finished = 0;
+    uint64_t seq0 = 0;  // place of batch 0 in the context-wide accumulation order (sample order across calls)
+    std::chrono::steady_clock::time_point t0;
+    std::vector<hipEvent_t> ext_events, tail_events;  // (begin, end) pairs of PT_RENDER_TIMED launches
 };
 
 }  // namespace
+
+struct pt_sched {
+    std::deque<RenderJob> jobs;   // submitted, not yet retired (front = oldest)
+    uint64_t next_seq = 0;        // sequence number the next submitted batch gets
+    uint64_t acc_seq = 0;         // sequence number of the next batch to be added to the accumulator
+    hipEvent_t ev_epoch = nullptr;  // time zero of the timed intervals below
+    std::vector<std::pair<float, float>> ext_iv, tail_iv;  // [begin, end) in ms since ev_epoch
+    double ext_sum = 0, tail_sum = 0;
+};
+
 
 struct pt_ctx {
     int device = -1;
@@ -93,11 +122,10 @@ struct pt_ctx {
     RenderLane lanes[kMaxLanes];
     hipStream_t tail_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t bulk_stream[kMaxLanes] = {};  // the round kernels of lane i run on bulk_stream[i % opt_bulk_streams]  // high priority: the few latency-bound tail waves go first
-    hipEvent_t last_acc_event = nullptr;
-    bool last_acc_valid = false;
-    std::vector<hipEvent_t> ext_events, tail_events;
+    hipStream_t acc_stream = nullptr;  // every k_accumulate, in batch order
+    pt_sched* sched = nullptr;         // calls in flight (pt_render_async) and their timed intervals
     DevBuf d_counters;
-    double extend_ms = 0, render_ms = 0, tail_ms = 0;
+    double render_ms = 0;
     uint64_t extend_launches = 0, tail_launches = 0;
     uint64_t opt_batch_slots = 0 /* 0 = the mode's default */, opt_tail_min = kTailMinPaths, opt_tail_fraction = kTailFraction, opt_lanes = 0 /* 0 = the mode's default */, opt_tail_streams = 4, opt_tail_paths_per_lane = 4, opt_first_check = 3, opt_simple_extend = 0, opt_bulk_streams = kMaxLanes, opt_tail_mode = 0, opt_render_mode = 1;
     std::vector<uint32_t> round_sizes;  // queue length of every round of the last finished batch
@@ -114,6 +142,8 @@ struct pt_ctx {
         if (e_ != hipSuccess)                                                                              \
             return (ctx)->fail(PT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));             \
     } while (0)
+
+static int drain(pt_ctx* c);  // wait for every call submitted with pt_render_async (defined with the scheduler below)
 
 static int dev_alloc(pt_ctx* c, DevBuf& b, size_t bytes) {
     if (b.p && b.bytes >= bytes) return PT_OK;
@@ -172,6 +202,11 @@ int pt_create(int device, pt_ctx** out) {
                 return PT_ERR_HIP;
             }
     }
+    c->sched = new pt_sched();
+    if (hipStreamCreateWithFlags(&c->acc_stream, hipStreamNonBlocking) != hipSuccess) {
+        pt_destroy(c);
+        return PT_ERR_HIP;
+    }
     if (dev_alloc(c, c->d_counters, CNT_N * sizeof(unsigned long long)) != PT_OK ||
         hipMemset(c->d_counters.p, 0, CNT_N * sizeof(unsigned long long)) != hipSuccess) {
         pt_destroy(c);
@@ -190,7 +225,14 @@ int pt_create(int device, pt_ctx** out) {
 void pt_destroy(pt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->sched) (void)drain(c);
     (void)hipDeviceSynchronize();
+    if (c->sched) {
+        if (c->sched->ev_epoch) (void)hipEventDestroy(c->sched->ev_epoch);
+        delete c->sched;
+        c->sched = nullptr;
+    }
+    if (c->acc_stream) (void)hipStreamDestroy(c->acc_stream);
     DevBuf* bufs[] = {&c->d_pairs, &c->d_prim, &c->d_meta, &c->d_nrm, &c->d_big, &c->d_mats, &c->d_sky, &c->d_lights, &c->d_cam,
                       &c->d_accum, &c->d_spill, &c->d_counters};
     for (DevBuf* b : bufs) b->release();
@@ -212,6 +254,7 @@ void pt_destroy(pt_ctx* c) {
 int pt_set_materials(pt_ctx* c, const pt_material* m, uint32_t count) {
     if (!c) return PT_ERR_INVALID;
     if (!m || count == 0) return c->fail(PT_ERR_INVALID, "pt_set_materials: empty material table");
+    if (int rc = drain(c)) return rc;  // calls in flight still read the old scene
     if (count > kMaxMaterials) return c->fail(PT_ERR_LIMIT, "pt_set_materials: more than 32768 materials");
     for (uint32_t i = 0; i < count; ++i)
         if (m[i].kind > PT_MAT_EMISSIVE) return c->fail(PT_ERR_INVALID, "pt_set_materials: unknown material kind");
@@ -223,6 +266,7 @@ int pt_set_materials(pt_ctx* c, const pt_material* m, uint32_t count) {
 int pt_set_triangles(pt_ctx* c, const float* pos, const float* nrm, const uint32_t* mat_id, uint64_t n) {
     if (!c) return PT_ERR_INVALID;
     if (!pos || !nrm || !mat_id || n == 0) return c->fail(PT_ERR_INVALID, "pt_set_triangles: null input or zero triangles");
+    if (int rc = drain(c)) return rc;  // calls in flight still read the old scene
     if (n > kMaxPrims) return c->fail(PT_ERR_LIMIT, "pt_set_triangles: more than 2^26 primitives");
     c->prim_kind = PRIM_TRIANGLE;
     c->pos.assign(pos, pos + 9 * n);
@@ -236,6 +280,7 @@ int pt_set_triangles(pt_ctx* c, const float* pos, const float* nrm, const uint32
 int pt_set_spheres(pt_ctx* c, const float* cr, const uint32_t* mat_id, uint64_t n) {
     if (!c) return PT_ERR_INVALID;
     if (!cr || !mat_id || n == 0) return c->fail(PT_ERR_INVALID, "pt_set_spheres: null input or zero spheres");
+    if (int rc = drain(c)) return rc;  // calls in flight still read the old scene
     if (n > kMaxPrims) return c->fail(PT_ERR_LIMIT, "pt_set_spheres: more than 2^26 primitives");
     c->prim_kind = PRIM_SPHERE;
     c->cr.assign(cr, cr + 4 * n);
@@ -249,6 +294,7 @@ int pt_set_spheres(pt_ctx* c, const float* cr, const uint32_t* mat_id, uint64_t 
 int pt_set_sky(pt_ctx* c, const float* rgb, uint32_t w, uint32_t h) {
     if (!c) return PT_ERR_INVALID;
     if (!rgb || w == 0 || h == 0) return c->fail(PT_ERR_INVALID, "pt_set_sky: null or empty image");
+    if (int rc = drain(c)) return rc;  // calls in flight still read the old scene
     PT_HIP(c, hipSetDevice(c->device));
     // pad with zeros up to the largest index the unclamped lookup can produce (scene.rs:163-166,174)
     const size_t n = (size_t)w * h * 3;
@@ -268,6 +314,7 @@ static int finalize_scene(pt_ctx* c);
 int pt_build(pt_ctx* c) {
     if (!c) return PT_ERR_INVALID;
     if (c->prim_kind < 0) return c->fail(PT_ERR_STATE, "pt_build: no primitives set");
+    if (int rc = drain(c)) return rc;
     if (c->mats.empty()) return c->fail(PT_ERR_STATE, "pt_build: no materials set");
     const uint64_t n = c->mat_id.size();
     std::vector<PrimInfo> info;
@@ -281,6 +328,7 @@ int pt_build(pt_ctx* c) {
 int pt_set_bvh(pt_ctx* c, const pt_bvh_node* nodes, uint64_t n_nodes, const uint64_t* indices, uint64_t n_indices) {
     if (!c) return PT_ERR_INVALID;
     if (c->prim_kind < 0) return c->fail(PT_ERR_STATE, "pt_set_bvh: no primitives set");
+    if (int rc = drain(c)) return rc;
     if (c->mats.empty()) return c->fail(PT_ERR_STATE, "pt_set_bvh: no materials set");
     const uint64_t n = c->mat_id.size();
     if (!nodes || !indices || n_nodes == 0 || n_indices != n) return c->fail(PT_ERR_INVALID, "pt_set_bvh: bad arguments");
@@ -309,7 +357,15 @@ int pt_set_bvh(pt_ctx* c, const pt_bvh_node* nodes, uint64_t n_nodes, const uint
         }
     }
     for (uint64_t i = 0; i < n; ++i)
+        if (!covered[i]) return c->fail(PT_ERR_BVH, "pt_set_bvh: leaves do not cover every index (a primitive would vanish)");
+    // indices must be a permutation of [0, n): a duplicate would leave another primitive out and
+    // point the light / material tables at the wrong slot
+    std::vector<uint8_t> used(n, 0);
+    for (uint64_t i = 0; i < n; ++i) {
         if (indices[i] >= n) return c->fail(PT_ERR_INVALID, "pt_set_bvh: primitive index out of range");
+        if (used[indices[i]]) return c->fail(PT_ERR_BVH, "pt_set_bvh: indices is not a permutation (duplicate entry)");
+        used[indices[i]] = 1;
+    }
     c->bvh.nodes.assign(nodes, nodes + n_nodes);
     c->bvh.indices.resize(n);
     for (uint64_t i = 0; i < n; ++i) c->bvh.indices[i] = (uint32_t)indices[i];
@@ -444,7 +500,9 @@ int pt_set_camera(pt_ctx* c, const float origin[3], const float target[3], uint3
     if (!c) return PT_ERR_INVALID;
     if (!c->built) return c->fail(PT_ERR_STATE, "pt_set_camera: call pt_build first");
     if (!origin || !target || width == 0 || height == 0) return c->fail(PT_ERR_INVALID, "pt_set_camera: bad arguments");
-    if ((uint64_t)width * height >= kMaxSlots) return c->fail(PT_ERR_LIMIT, "pt_set_camera: image too large");
+    if ((((uint64_t)width + 7) & ~7ull) * (((uint64_t)height + 7) & ~7ull) >= kMaxSlots)  // padded to whole 8x8 pixel tiles
+        return c->fail(PT_ERR_LIMIT, "pt_set_camera: image too large");
+    if (int rc = drain(c)) return rc;
     PT_HIP(c, hipSetDevice(c->device));
     DevCamera cam{};
     for (int a = 0; a < 3; ++a) {
@@ -485,6 +543,7 @@ int pt_get_camera(const pt_ctx* c, pt_camera_state* out) {
 int pt_reset_accum(pt_ctx* c) {
     if (!c) return PT_ERR_INVALID;
     if (!c->have_cam) return c->fail(PT_ERR_STATE, "pt_reset_accum: no camera");
+    if (int rc = drain(c)) return rc;
     PT_HIP(c, hipSetDevice(c->device));
     PT_HIP(c, hipMemsetAsync(c->d_accum.p, 0, (size_t)c->cam.width * c->cam.height * 3 * sizeof(float), c->stream));
     PT_HIP(c, hipStreamSynchronize(c->stream));
@@ -599,33 +658,37 @@ static int lane_alloc(pt_ctx* c, RenderLane& L, uint64_t slots, uint32_t rounds)
     return PT_OK;
 }
 
-namespace {
-struct RenderJob {
-    PixelMap M;
-    uint32_t max_depth, rounds, k0, k1;
-    bool timed, count;
-    uint32_t tail_threshold;
-};
-}  // namespace
+static void destroy_events(std::vector<hipEvent_t>& v) {
+    for (hipEvent_t e : v) (void)hipEventDestroy(e);
+    v.clear();
+}
+
+static int timed_begin(pt_ctx* c, RenderJob& J, std::vector<hipEvent_t>& list, hipStream_t st) {
+    if (!J.timed) return PT_OK;
+    hipEvent_t a, b;
+    PT_HIP(c, hipEventCreate(&a));
+    PT_HIP(c, hipEventCreate(&b));
+    list.push_back(a);
+    list.push_back(b);
+    PT_HIP(c, hipEventRecord(a, st));
+    return PT_OK;
+}
+static int timed_end(pt_ctx* c, RenderJob& J, std::vector<hipEvent_t>& list, hipStream_t st) {
+    if (!J.timed) return PT_OK;
+    PT_HIP(c, hipEventRecord(list.back(), st));
+    return PT_OK;
+}
 
 // enqueue rounds [L.round, upto) of the lane's batch, then an async read-back of the next queue length
-static int lane_issue_rounds(pt_ctx* c, RenderLane& L, const RenderJob& J, uint32_t upto) {
+static int lane_issue_rounds(pt_ctx* c, RenderLane& L, RenderJob& J, uint32_t upto) {
     uint32_t* q[2] = {(uint32_t*)L.d_q0.p, (uint32_t*)L.d_q1.p};
     uint32_t* qn = (uint32_t*)L.d_qn.p;
     unsigned long long* counters = (unsigned long long*)c->d_counters.p;
+    int rc;
     for (uint32_t r = L.round; r < upto; ++r) {
-        if (J.timed) {
-            hipEvent_t a, b;
-            PT_HIP(c, hipEventCreate(&a));
-            PT_HIP(c, hipEventCreate(&b));
-            PT_HIP(c, hipEventRecord(a, L.stream));
-            launch_extend(c->prim_kind, J.count, c->opt_simple_extend != 0, c->ds, L.ps, q[r & 1], qn + r, qn + J.rounds + 2 + r, L.cfg, counters, L.stream);
-            PT_HIP(c, hipEventRecord(b, L.stream));
-            c->ext_events.push_back(a);
-            c->ext_events.push_back(b);
-        } else {
-            launch_extend(c->prim_kind, J.count, c->opt_simple_extend != 0, c->ds, L.ps, q[r & 1], qn + r, qn + J.rounds + 2 + r, L.cfg, counters, L.stream);
-        }
+        if ((rc = timed_begin(c, J, J.ext_events, L.stream))) return rc;
+        launch_extend(c->prim_kind, J.count, c->opt_simple_extend != 0, c->ds, L.ps, q[r & 1], qn + r, qn + J.rounds + 2 + r, L.cfg, counters, L.stream);
+        if ((rc = timed_end(c, J, J.ext_events, L.stream))) return rc;
         c->extend_launches += 1;
         launch_shade(c->prim_kind, c->nee, c->ds, L.ps, J.M, q[r & 1], qn + r, q[(r + 1) & 1], qn + r + 1, J.max_depth, L.sample_base,
                      J.k0, J.k1, L.cfg, counters, L.stream);
@@ -637,8 +700,9 @@ static int lane_issue_rounds(pt_ctx* c, RenderLane& L, const RenderJob& J, uint3
     return PT_OK;
 }
 
-static int lane_start(pt_ctx* c, RenderLane& L, const RenderJob& J, uint32_t batch, uint32_t ns, uint32_t sample_base) {
+static int lane_start(pt_ctx* c, RenderLane& L, RenderJob& J, uint32_t batch, uint32_t ns, uint32_t sample_base) {
     uint32_t* qn = (uint32_t*)L.d_qn.p;
+    int rc;
     L.batch = batch;
     L.ns = ns;
     L.sample_base = sample_base;
@@ -647,19 +711,10 @@ static int lane_start(pt_ctx* c, RenderLane& L, const RenderJob& J, uint32_t bat
     PT_HIP(c, hipMemsetAsync(qn, 0, (size_t)(J.rounds + 2) * 8 + 64, L.stream));
     if (c->opt_render_mode == 1) {
         // the whole batch in one persistent kernel (generate + sample, state in registers)
-        hipEvent_t a = nullptr, b = nullptr;
-        if (J.timed) {
-            PT_HIP(c, hipEventCreate(&a));
-            PT_HIP(c, hipEventCreate(&b));
-            PT_HIP(c, hipEventRecord(a, L.stream));
-        }
+        if ((rc = timed_begin(c, J, J.tail_events, L.stream))) return rc;
         launch_path(c->prim_kind, c->nee, J.count, c->ds, (const DevCamera*)c->d_cam.p, J.M, ns, sample_base, J.max_depth, J.k0, J.k1,
                     L.ps.out, qn + 2 * (J.rounds + 2), L.cfg, (unsigned long long*)c->d_counters.p, L.stream);
-        if (J.timed) {
-            PT_HIP(c, hipEventRecord(b, L.stream));
-            c->tail_events.push_back(a);
-            c->tail_events.push_back(b);
-        }
+        if ((rc = timed_end(c, J, J.tail_events, L.stream))) return rc;
         c->tail_launches += 1;
         PT_HIP(c, hipEventRecord(L.ev_check, L.stream));
         PT_HIP(c, hipGetLastError());
@@ -676,13 +731,14 @@ static int lane_start(pt_ctx* c, RenderLane& L, const RenderJob& J, uint32_t bat
     return lane_issue_rounds(c, L, J, std::min<uint32_t>((uint32_t)c->opt_first_check, J.rounds));
 }
 
-// No stream ever waits on an event of another stream that is still pending: streams share hardware
-// queues, and a barrier packet waiting for work queued behind another such barrier would deadlock.
-// The host therefore polls (ev_check / ev_done) and only then enqueues the dependent work.
+// No stream ever waits on an event of another stream that is still pending (DESIGN.md section 6 has
+// the history): the host polls ev_check / ev_done and only then enqueues the dependent work, so no
+// hardware queue ever holds a blocked barrier packet.
 
 // The paths still alive after the rounds go to the batch's tail stream (ev_check has completed).
-static int lane_tail(pt_ctx* c, RenderLane& L, const RenderJob& J, uint32_t live) {
+static int lane_tail(pt_ctx* c, RenderLane& L, RenderJob& J, uint32_t live) {
     hipStream_t ts = c->tail_stream[L.batch % c->opt_tail_streams];
+    int rc;
     if (live != 0 && L.round < J.rounds && c->opt_tail_mode == 1) {
         // tail as further wavefront rounds, all enqueued blindly on the tail stream with a grid sized
         // for the few paths left (rounds that find an empty queue cost a few microseconds)
@@ -692,18 +748,9 @@ static int lane_tail(pt_ctx* c, RenderLane& L, const RenderJob& J, uint32_t live
         LaunchCfg small = L.cfg;
         small.grid = std::min<uint32_t>(L.cfg.grid, std::max<uint32_t>(16, (live + kTraceBlock - 1) / kTraceBlock));
         for (uint32_t r = L.round; r < J.rounds; ++r) {
-            if (J.timed) {
-                hipEvent_t a, b;
-                PT_HIP(c, hipEventCreate(&a));
-                PT_HIP(c, hipEventCreate(&b));
-                PT_HIP(c, hipEventRecord(a, ts));
-                launch_extend(c->prim_kind, J.count, c->opt_simple_extend != 0, c->ds, L.ps, q[r & 1], qn + r, qn + J.rounds + 2 + r, small, counters, ts);
-                PT_HIP(c, hipEventRecord(b, ts));
-                c->ext_events.push_back(a);
-                c->ext_events.push_back(b);
-            } else {
-                launch_extend(c->prim_kind, J.count, c->opt_simple_extend != 0, c->ds, L.ps, q[r & 1], qn + r, qn + J.rounds + 2 + r, small, counters, ts);
-            }
+            if ((rc = timed_begin(c, J, J.ext_events, ts))) return rc;
+            launch_extend(c->prim_kind, J.count, c->opt_simple_extend != 0, c->ds, L.ps, q[r & 1], qn + r, qn + J.rounds + 2 + r, small, counters, ts);
+            if ((rc = timed_end(c, J, J.ext_events, ts))) return rc;
             c->extend_launches += 1;
             launch_shade(c->prim_kind, c->nee, c->ds, L.ps, J.M, q[r & 1], qn + r, q[(r + 1) & 1], qn + r + 1, J.max_depth, L.sample_base,
                          J.k0, J.k1, small, counters, ts);
@@ -711,19 +758,10 @@ static int lane_tail(pt_ctx* c, RenderLane& L, const RenderJob& J, uint32_t live
         L.round = J.rounds;
     } else if (live != 0 && L.round < J.rounds) {
         uint32_t* qn = (uint32_t*)L.d_qn.p;
-        hipEvent_t a = nullptr, b = nullptr;
-        if (J.timed) {
-            PT_HIP(c, hipEventCreate(&a));
-            PT_HIP(c, hipEventCreate(&b));
-            PT_HIP(c, hipEventRecord(a, ts));
-        }
+        if ((rc = timed_begin(c, J, J.tail_events, ts))) return rc;
         launch_tail(c->prim_kind, c->nee, J.count, (int)c->opt_tail_mode, c->ds, L.ps, (L.round & 1) ? (uint32_t*)L.d_q1.p : (uint32_t*)L.d_q0.p, qn + L.round,
                     qn + 2 * J.rounds + 3, (uint32_t)((live + c->opt_tail_paths_per_lane - 1) / c->opt_tail_paths_per_lane), J.max_depth, J.k0, J.k1, L.cfg, (unsigned long long*)c->d_counters.p, ts);
-        if (J.timed) {
-            PT_HIP(c, hipEventRecord(b, ts));
-            c->tail_events.push_back(a);
-            c->tail_events.push_back(b);
-        }
+        if ((rc = timed_end(c, J, J.tail_events, ts))) return rc;
         c->tail_launches += 1;
     }
     PT_HIP(c, hipEventRecord(L.ev_check, ts));
@@ -732,25 +770,202 @@ static int lane_tail(pt_ctx* c, RenderLane& L, const RenderJob& J, uint32_t live
     return PT_OK;
 }
 
-// All paths of the batch are finished and the previous batch has been added: add this batch's samples.
-static int lane_accumulate(pt_ctx* c, RenderLane& L, const RenderJob& J) {
-    hipStream_t ts = c->tail_stream[L.batch % c->opt_tail_streams];
-    launch_accumulate(J.M, L.ps.out, L.ns, c->opt_render_mode == 1, (float*)c->d_accum.p, ts);
-    PT_HIP(c, hipEventRecord(L.ev_done, ts));
+// All paths of the batch are finished: add its samples.  Every accumulate runs on the one
+// accumulate stream and the host enqueues them in batch order, so every pixel's sum is built in
+// sample order (main.rs:159 adds one frame at a time) across batches and across calls.
+static int lane_accumulate(pt_ctx* c, RenderLane& L, RenderJob& J) {
+    launch_accumulate(J.M, L.ps.out, L.ns, c->opt_render_mode == 1, (float*)c->d_accum.p, c->acc_stream);
+    PT_HIP(c, hipEventRecord(L.ev_done, c->acc_stream));
     PT_HIP(c, hipGetLastError());
-    c->last_acc_event = L.ev_done;
-    c->last_acc_valid = true;
     L.state = RenderLane::DRAINING;
     return PT_OK;
 }
 
-int pt_render(pt_ctx* c, uint32_t spp, uint32_t max_depth, uint64_t seed, const pt_shard* shard, uint32_t flags) {
+// total length of the union of [begin, end) intervals
+static double union_ms(std::vector<std::pair<float, float>> iv) {
+    std::sort(iv.begin(), iv.end());
+    double total = 0;
+    float lo = 0, hi = 0;
+    bool open = false;
+    for (const auto& p : iv) {
+        if (open && p.first <= hi) {
+            hi = std::max(hi, p.second);
+        } else {
+            if (open) total += (double)hi - lo;
+            lo = p.first;
+            hi = p.second;
+            open = true;
+        }
+    }
+    if (open) total += (double)hi - lo;
+    return total;
+}
+
+// a finished job leaves the queue: its timed intervals are kept relative to the context's epoch event
+static int retire_job(pt_ctx* c, RenderJob& J) {
+    pt_sched& S = *c->sched;
+    c->render_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - J.t0).count();
+    for (int which = 0; which < 2; ++which) {
+        std::vector<hipEvent_t>& ev = which ? J.tail_events : J.ext_events;
+        for (size_t i = 0; i + 1 < ev.size(); i += 2) {
+            float b = 0.f, e = 0.f, d = 0.f;
+            PT_HIP(c, hipEventElapsedTime(&b, S.ev_epoch, ev[i]));
+            PT_HIP(c, hipEventElapsedTime(&e, S.ev_epoch, ev[i + 1]));
+            PT_HIP(c, hipEventElapsedTime(&d, ev[i], ev[i + 1]));
+            (which ? S.tail_iv : S.ext_iv).push_back({b, std::max(e, b)});
+            (which ? S.tail_sum : S.ext_sum) += d;
+        }
+        destroy_events(ev);
+    }
+    return PT_OK;
+}
+
+// Something failed while jobs were in flight: let the device finish whatever is queued, drop all
+// jobs and put every lane back to IDLE, so that the next call starts from a clean state.
+static int abort_jobs(pt_ctx* c, int rc) {
+    pt_sched& S = *c->sched;
+    const std::string keep = c->err;
+    (void)hipDeviceSynchronize();
+    for (RenderJob& J : S.jobs) {
+        destroy_events(J.ext_events);
+        destroy_events(J.tail_events);
+    }
+    S.jobs.clear();
+    S.acc_seq = S.next_seq;
+    for (RenderLane& L : c->lanes) {
+        L.state = RenderLane::IDLE;
+        L.job = nullptr;
+    }
+    c->err = keep;
+    return rc;
+}
+
+// One pass of the scheduler over all lanes; never blocks.  Batches of all queued calls share the
+// lanes, so the end of one call's last kernel (a few long paths in nearly empty waves) overlaps the
+// start of the next call's.
+static int pump_once(pt_ctx* c, bool& progressed) {
+    pt_sched& S = *c->sched;
+    uint32_t busy = 0;
+    for (const RenderLane& L : c->lanes) busy += L.state != RenderLane::IDLE;
+    for (uint32_t i = 0; i < kMaxLanes; ++i) {
+        RenderLane& L = c->lanes[i];
+        if (L.state == RenderLane::IDLE) {
+            RenderJob* J = nullptr;
+            for (RenderJob& cand : S.jobs)
+                if (cand.next_batch < cand.n_batches) { J = &cand; break; }
+            if (!J || busy >= J->max_lanes) continue;
+            int rc = lane_alloc(c, L, J->batch_slots, J->rounds);
+            if (rc) return rc;
+            hipStream_t& bs = c->bulk_stream[i % c->opt_bulk_streams];
+            if (!bs) PT_HIP(c, hipStreamCreateWithFlags(&bs, hipStreamNonBlocking));
+            L.stream = bs;
+            L.job = J;
+            L.seq = J->seq0 + J->next_batch;
+            const uint64_t done = (uint64_t)J->next_batch * J->per_batch;
+            const uint32_t ns = (uint32_t)std::min<uint64_t>(J->per_batch, J->spp - done);
+            rc = lane_start(c, L, *J, J->next_batch, ns, J->sample_begin + (uint32_t)done);
+            if (rc) return rc;
+            J->next_batch += 1;
+            busy += 1;
+            progressed = true;
+            continue;
+        }
+        RenderJob& J = *L.job;
+        if (L.state == RenderLane::RUNNING) {
+            hipError_t q = hipEventQuery(L.ev_check);
+            if (q == hipErrorNotReady) continue;
+            if (q != hipSuccess) return c->fail(PT_ERR_HIP, std::string("pt_render: ") + hipGetErrorString(q));
+            progressed = true;
+            const uint32_t live = *L.h_qn;
+            int rc = PT_OK;
+            if (live == 0 || L.round >= J.rounds) {
+                L.state = RenderLane::READY;
+            } else if (live <= J.tail_threshold) {
+                rc = lane_tail(c, L, J, live);
+            } else {
+                rc = lane_issue_rounds(c, L, J, std::min<uint32_t>(L.round + 2, J.rounds));
+            }
+            if (rc) return rc;
+        } else if (L.state == RenderLane::TAILING) {
+            hipError_t q = hipEventQuery(L.ev_check);
+            if (q == hipErrorNotReady) continue;
+            if (q != hipSuccess) return c->fail(PT_ERR_HIP, std::string("pt_render: ") + hipGetErrorString(q));
+            L.state = RenderLane::READY;
+            progressed = true;
+        }
+        if (L.state == RenderLane::READY && L.seq == S.acc_seq) {
+            int rc = lane_accumulate(c, L, J);
+            if (rc) return rc;
+            S.acc_seq += 1;
+            progressed = true;
+        } else if (L.state == RenderLane::DRAINING) {
+            hipError_t q = hipEventQuery(L.ev_done);
+            if (q == hipErrorNotReady) continue;
+            if (q != hipSuccess) return c->fail(PT_ERR_HIP, std::string("pt_render: ") + hipGetErrorString(q));
+            if (J.count) {  // diagnostics: queue length per round of the last finished batch
+                c->round_sizes.assign(J.rounds + 1, 0);
+                PT_HIP(c, hipMemcpy(c->round_sizes.data(), L.d_qn.p, (size_t)(J.rounds + 1) * 4, hipMemcpyDeviceToHost));
+            }
+            L.state = RenderLane::IDLE;
+            L.job = nullptr;
+            J.finished += 1;
+            busy -= 1;
+            progressed = true;
+        }
+    }
+    while (!S.jobs.empty() && S.jobs.front().finished == S.jobs.front().n_batches) {
+        int rc = retire_job(c, S.jobs.front());
+        if (rc) return rc;
+        S.jobs.pop_front();
+        progressed = true;
+    }
+    return PT_OK;
+}
+
+// Run the scheduler until every submitted call has finished.  The host thread only enqueues and
+// polls; between polls it yields at first and then sleeps (5 us doubling up to 100 us), so a long
+// kernel does not cost a spinning core.
+static int drain(pt_ctx* c) {
+    pt_sched& S = *c->sched;
+    if (S.jobs.empty()) return PT_OK;
+    PT_HIP(c, hipSetDevice(c->device));
+    const bool dbg = std::getenv("PTCORE_DEBUG") != nullptr;
+    uint32_t idle_polls = 0;
+    auto last_report = std::chrono::steady_clock::now();
+    while (!S.jobs.empty()) {
+        bool progressed = false;
+        int rc = pump_once(c, progressed);
+        if (rc) return abort_jobs(c, rc);
+        if (progressed) {
+            idle_polls = 0;
+            continue;
+        }
+        idle_polls += 1;
+        if (idle_polls < 64) {
+            std::this_thread::yield();
+        } else {
+            const uint32_t step = std::min<uint32_t>((idle_polls - 64) / 16, 5);  // 5, 10, 20, 40, 80, 100 us
+            std::this_thread::sleep_for(std::chrono::microseconds(std::min<uint32_t>(5u << step, 100u)));
+        }
+        if (dbg && std::chrono::steady_clock::now() - last_report > std::chrono::seconds(2)) {
+            last_report = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "[ptcore] waiting: %zu calls queued, next batch to add %llu, lanes", S.jobs.size(), (unsigned long long)S.acc_seq);
+            for (const RenderLane& L : c->lanes) std::fprintf(stderr, " %d(#%llu)", (int)L.state, (unsigned long long)L.seq);
+            std::fprintf(stderr, "\n");
+        }
+    }
+    return PT_OK;
+}
+
+int pt_render_async(pt_ctx* c, uint32_t spp, uint32_t max_depth, uint64_t seed, const pt_shard* shard, uint32_t flags) {
     if (!c) return PT_ERR_INVALID;
+    if (!c->built) return c->fail(PT_ERR_STATE, "pt_render: scene changed since pt_build (or never built): call pt_build first");
     if (!c->have_cam) return c->fail(PT_ERR_STATE, "pt_render: call pt_set_camera first");
     if (!c->ds.sky) return c->fail(PT_ERR_STATE, "pt_render: call pt_set_sky first");
     if (max_depth > kMaxDepth) return c->fail(PT_ERR_LIMIT, "pt_render: max_depth above 65535");
     if (spp == 0) return PT_OK;
     PT_HIP(c, hipSetDevice(c->device));
+    pt_sched& S = *c->sched;
 
     RenderJob J{};
     PixelMap& M = J.M;
@@ -772,6 +987,10 @@ int pt_render(pt_ctx* c, uint32_t spp, uint32_t max_depth, uint64_t seed, const 
             return c->fail(PT_ERR_INVALID, "pt_render: unknown shard kind");
         }
     }
+    {   // the tile-padded pixel count must fit the 32-bit slot arithmetic of the kernels
+        const uint64_t tx = ((uint64_t)M.width + M.tile - 1) / M.tile, ty = ((uint64_t)M.height + M.tile - 1) / M.tile;
+        if (tx * ty * M.tile * M.tile >= kMaxSlots) return c->fail(PT_ERR_LIMIT, "pt_render: tile-padded image too large");
+    }
     pixelmap_init(M, M.width, M.height, M.tile, M.rank, M.nranks);
     if (M.npix_pad == 0) {  // this rank owns no tile
         c->spp += (float)spp;
@@ -783,137 +1002,56 @@ int pt_render(pt_ctx* c, uint32_t spp, uint32_t max_depth, uint64_t seed, const 
     uint64_t per_batch = std::max<uint64_t>(1, want_slots / M.npix_pad);
     per_batch = std::min<uint64_t>(per_batch, spp);
     if (per_batch * M.npix_pad >= kMaxSlots) return c->fail(PT_ERR_LIMIT, "pt_render: batch too large");
-    const uint64_t batch_slots = per_batch * M.npix_pad;
-    const uint32_t n_batches = (uint32_t)((spp + per_batch - 1) / per_batch);
-    // path-kernel mode: two launches in flight cover each other's ends (more measured no faster) and bound the
-    // radiance slabs to 2 x 8 GB; the wavefront rounds need all eight
-    const uint64_t want_lanes = c->opt_lanes ? c->opt_lanes : (c->opt_render_mode == 1 ? 2 : kMaxLanes);
-    const uint32_t n_lanes = (uint32_t)std::min<uint64_t>(want_lanes, n_batches);
+    J.per_batch = per_batch;
+    J.batch_slots = per_batch * M.npix_pad;
+    J.n_batches = (uint32_t)((spp + per_batch - 1) / per_batch);
+    // path-kernel mode: two launches in flight cover each other's ends when the batches are large (more measured
+    // no faster, and the radiance slabs stay within 2 x 8 GB); small batches (few samples per call) are mostly
+    // end, so up to eight of them overlap.  The wavefront rounds need all eight.
+    uint64_t want_lanes = c->opt_lanes;
+    if (!want_lanes) want_lanes = c->opt_render_mode == 1 ? std::min<uint64_t>(kMaxLanes, std::max<uint64_t>(2, kPathBatchSlots / 4 / J.batch_slots)) : kMaxLanes;
+    J.max_lanes = (uint32_t)want_lanes;
+    J.spp = spp;
+    J.sample_begin = sample_begin;
     J.max_depth = max_depth;
     J.rounds = max_depth == 0 ? 0 : 2 * max_depth;  // each iteration traces at most twice
     J.k0 = (uint32_t)seed;
     J.k1 = (uint32_t)(seed >> 32);
     J.timed = (flags & PT_RENDER_TIMED) != 0;
     J.count = (flags & PT_RENDER_COUNT) != 0;
-    J.tail_threshold = c->opt_tail_fraction == 0 ? 0 : (uint32_t)std::max<uint64_t>(c->opt_tail_min, batch_slots / c->opt_tail_fraction);
-    for (uint32_t i = 0; i < n_lanes; ++i) {
-        int rc = lane_alloc(c, c->lanes[i], batch_slots, J.rounds);
-        if (rc) return rc;
-        hipStream_t& bs = c->bulk_stream[i % c->opt_bulk_streams];
-        if (!bs) PT_HIP(c, hipStreamCreateWithFlags(&bs, hipStreamNonBlocking));
-        c->lanes[i].stream = bs;
-        c->lanes[i].state = RenderLane::IDLE;
+    J.tail_threshold = c->opt_tail_fraction == 0 ? 0 : (uint32_t)std::max<uint64_t>(c->opt_tail_min, J.batch_slots / c->opt_tail_fraction);
+    J.seq0 = S.next_seq;
+    J.t0 = std::chrono::steady_clock::now();
+    if (J.timed && !S.ev_epoch) {
+        PT_HIP(c, hipEventCreate(&S.ev_epoch));
+        PT_HIP(c, hipEventRecord(S.ev_epoch, c->stream));
+        PT_HIP(c, hipStreamSynchronize(c->stream));
     }
-
-    hipEvent_t ev_begin, ev_end;
-    PT_HIP(c, hipEventCreate(&ev_begin));
-    PT_HIP(c, hipEventCreate(&ev_end));
-    PT_HIP(c, hipEventRecord(ev_begin, c->stream));
-    for (uint32_t i = 0; i < n_lanes; ++i) PT_HIP(c, hipStreamWaitEvent(c->lanes[i].stream, ev_begin, 0));
-    for (hipStream_t t : c->tail_stream) PT_HIP(c, hipStreamWaitEvent(t, ev_begin, 0));
-    c->last_acc_valid = false;
-    c->ext_events.clear();
-    c->tail_events.clear();
-
-    uint32_t next_batch = 0, finished = 0, next_acc = 0;
-    const bool dbg = std::getenv("PTCORE_DEBUG") != nullptr;
-    uint64_t spins = 0;
-    while (finished < n_batches) {
-        bool progressed = false;
-        for (uint32_t i = 0; i < n_lanes; ++i) {
-            RenderLane& L = c->lanes[i];
-            if (L.state == RenderLane::IDLE && next_batch < n_batches) {
-                const uint32_t done = next_batch * (uint32_t)per_batch;
-                const uint32_t ns = (uint32_t)std::min<uint64_t>(per_batch, spp - done);
-                int rc = lane_start(c, L, J, next_batch, ns, sample_begin + done);
-                if (rc) return rc;
-                next_batch += 1;
-                progressed = true;
-            } else if (L.state == RenderLane::RUNNING) {
-                hipError_t q = hipEventQuery(L.ev_check);
-                if (q == hipErrorNotReady) continue;
-                if (q != hipSuccess) return c->fail(PT_ERR_HIP, std::string("pt_render: ") + hipGetErrorString(q));
-                progressed = true;
-                const uint32_t live = *L.h_qn;
-                int rc = PT_OK;
-                if (live == 0 || L.round >= J.rounds) {
-                    L.state = RenderLane::READY;
-                } else if (live <= J.tail_threshold) {
-                    rc = lane_tail(c, L, J, live);
-                } else {
-                    rc = lane_issue_rounds(c, L, J, std::min<uint32_t>(L.round + 2, J.rounds));
-                }
-                if (rc) return rc;
-            } else if (L.state == RenderLane::TAILING) {
-                hipError_t q = hipEventQuery(L.ev_check);
-                if (q == hipErrorNotReady) continue;
-                if (q != hipSuccess) return c->fail(PT_ERR_HIP, std::string("pt_render: ") + hipGetErrorString(q));
-                L.state = RenderLane::READY;
-                progressed = true;
-            }
-            if (L.state == RenderLane::READY && L.batch == next_acc) {
-                // batches are added in order so every pixel's sum is built in sample order
-                if (c->last_acc_valid) {
-                    hipError_t q = hipEventQuery(c->last_acc_event);
-                    if (q == hipErrorNotReady) continue;
-                    if (q != hipSuccess) return c->fail(PT_ERR_HIP, std::string("pt_render: ") + hipGetErrorString(q));
-                }
-                int rc = lane_accumulate(c, L, J);
-                if (rc) return rc;
-                next_acc += 1;
-                progressed = true;
-            } else if (L.state == RenderLane::DRAINING) {
-                hipError_t q = hipEventQuery(L.ev_done);
-                if (q == hipErrorNotReady) continue;
-                if (q != hipSuccess) return c->fail(PT_ERR_HIP, std::string("pt_render: ") + hipGetErrorString(q));
-                if (J.count) {  // diagnostics: queue length per round of the last finished batch
-                    c->round_sizes.assign(J.rounds + 1, 0);
-                    PT_HIP(c, hipMemcpy(c->round_sizes.data(), L.d_qn.p, (size_t)(J.rounds + 1) * 4, hipMemcpyDeviceToHost));
-                }
-                L.state = RenderLane::IDLE;
-                finished += 1;
-                progressed = true;
-            }
-        }
-        if (!progressed) {
-            std::this_thread::yield();
-            if (dbg && (++spins % 2000000) == 0) {
-                std::fprintf(stderr, "[ptcore] waiting: next_batch %u finished %u next_acc %u states", next_batch, finished, next_acc);
-                for (uint32_t i = 0; i < n_lanes; ++i) std::fprintf(stderr, " %d(b%u)", (int)c->lanes[i].state, c->lanes[i].batch);
-                std::fprintf(stderr, "\n");
-            }
-        }  // poll: any lane may be the next one to need the host
-    }
-    if (c->last_acc_valid) PT_HIP(c, hipStreamWaitEvent(c->stream, c->last_acc_event, 0));
-    PT_HIP(c, hipEventRecord(ev_end, c->stream));
-    PT_HIP(c, hipStreamSynchronize(c->stream));
-    float ms = 0.f;
-    PT_HIP(c, hipEventElapsedTime(&ms, ev_begin, ev_end));
-    c->render_ms += ms;
-    for (size_t i = 0; i + 1 < c->ext_events.size(); i += 2) {
-        float e = 0.f;
-        PT_HIP(c, hipEventElapsedTime(&e, c->ext_events[i], c->ext_events[i + 1]));
-        c->extend_ms += e;
-    }
-    for (size_t i = 0; i + 1 < c->tail_events.size(); i += 2) {
-        float e = 0.f;
-        PT_HIP(c, hipEventElapsedTime(&e, c->tail_events[i], c->tail_events[i + 1]));
-        c->tail_ms += e;
-    }
-    for (hipEvent_t e : c->ext_events) (void)hipEventDestroy(e);
-    for (hipEvent_t e : c->tail_events) (void)hipEventDestroy(e);
-    c->ext_events.clear();
-    c->tail_events.clear();
-    (void)hipEventDestroy(ev_begin);
-    (void)hipEventDestroy(ev_end);
+    S.next_seq += J.n_batches;
+    S.jobs.push_back(std::move(J));
     c->spp += (float)spp;
     c->samples_done = sample_begin + spp;
+    bool progressed = false;
+    int rc = pump_once(c, progressed);
+    if (rc) return abort_jobs(c, rc);
     return PT_OK;
+}
+
+int pt_wait(pt_ctx* c) {
+    if (!c) return PT_ERR_INVALID;
+    return drain(c);
+}
+
+int pt_render(pt_ctx* c, uint32_t spp, uint32_t max_depth, uint64_t seed, const pt_shard* shard, uint32_t flags) {
+    int rc = pt_render_async(c, spp, max_depth, seed, shard, flags);
+    if (rc) return rc;
+    return drain(c);
 }
 
 int pt_read_accum(pt_ctx* c, float* rgb, float* spp_out) {
     if (!c) return PT_ERR_INVALID;
     if (!c->have_cam) return c->fail(PT_ERR_STATE, "pt_read_accum: no camera");
+    if (int rc = drain(c)) return rc;
     PT_HIP(c, hipSetDevice(c->device));
     if (rgb) PT_HIP(c, hipMemcpy(rgb, c->d_accum.p, (size_t)c->cam.width * c->cam.height * 3 * sizeof(float), hipMemcpyDeviceToHost));
     if (spp_out) *spp_out = c->spp;
@@ -924,6 +1062,7 @@ int pt_write_accum(pt_ctx* c, const float* rgb, float spp) {
     if (!c) return PT_ERR_INVALID;
     if (!c->have_cam) return c->fail(PT_ERR_STATE, "pt_write_accum: no camera");
     if (!rgb || !(spp >= 0.0f) || spp > 4294967040.0f) return c->fail(PT_ERR_INVALID, "pt_write_accum: null image or bad sample count");
+    if (int rc = drain(c)) return rc;
     PT_HIP(c, hipSetDevice(c->device));
     PT_HIP(c, hipMemcpy(c->d_accum.p, rgb, (size_t)c->cam.width * c->cam.height * 3 * sizeof(float), hipMemcpyHostToDevice));
     c->spp = spp;
@@ -935,6 +1074,7 @@ int pt_read_rgb8(pt_ctx* c, uint8_t* rgb, uint64_t pitch) {
     if (!c) return PT_ERR_INVALID;
     if (!c->have_cam) return c->fail(PT_ERR_STATE, "pt_read_rgb8: no camera");
     if (!rgb || pitch < (uint64_t)c->cam.width * 3) return c->fail(PT_ERR_INVALID, "pt_read_rgb8: null pointer or pitch < 3 * width");
+    if (int rc = drain(c)) return rc;
     PT_HIP(c, hipSetDevice(c->device));
     DevBuf d;
     int rc = dev_alloc(c, d, (size_t)pitch * c->cam.height);
@@ -953,6 +1093,7 @@ int pt_read_rgb8(pt_ctx* c, uint8_t* rgb, uint64_t pitch) {
 int pt_accum_device_ptr(pt_ctx* c, void** ptr, uint64_t* n_floats) {
     if (!c || !ptr) return PT_ERR_INVALID;
     if (!c->have_cam) return c->fail(PT_ERR_STATE, "pt_accum_device_ptr: no camera");
+    if (int rc = drain(c)) return rc;  // the caller is about to read or reduce the sums
     *ptr = c->d_accum.p;
     if (n_floats) *n_floats = (uint64_t)c->cam.width * c->cam.height * 3;
     return PT_OK;
@@ -960,12 +1101,14 @@ int pt_accum_device_ptr(pt_ctx* c, void** ptr, uint64_t* n_floats) {
 
 int pt_add_external_samples(pt_ctx* c, float spp) {
     if (!c) return PT_ERR_INVALID;
+    if (int rc = drain(c)) return rc;
     c->spp += spp;
     return PT_OK;
 }
 
 int pt_get_counters(pt_ctx* c, pt_counters* out) {
     if (!c || !out) return PT_ERR_INVALID;
+    if (int rc = drain(c)) return rc;
     PT_HIP(c, hipSetDevice(c->device));
     unsigned long long cur[CNT_N];
     PT_HIP(c, hipMemcpy(cur, c->d_counters.p, sizeof(cur), hipMemcpyDeviceToHost));
@@ -986,15 +1129,20 @@ int pt_get_counters(pt_ctx* c, pt_counters* out) {
     out->tail_node_tests = cur[CNT_TAIL_NODE_TESTS];
     out->tail_prim_tests = cur[CNT_TAIL_PRIM_TESTS];
     out->tail_launches = c->tail_launches;
-    out->tail_ms = c->tail_ms;
+    // timed launches may overlap (several batches or calls in flight): *_ms is the time during which at least one
+    // such launch was running, *_ms_sum the plain sum of their durations (what a profiler's average x count gives)
+    out->tail_ms = union_ms(c->sched->tail_iv);
     out->extend_launches = c->extend_launches;
-    out->extend_ms = c->extend_ms;
+    out->extend_ms = union_ms(c->sched->ext_iv);
     out->render_ms = c->render_ms;
+    out->tail_ms_sum = c->sched->tail_sum;
+    out->extend_ms_sum = c->sched->ext_sum;
     return PT_OK;
 }
 
 int pt_get_round_stats(pt_ctx* c, uint32_t* queue_sizes, uint32_t cap, uint32_t* n_rounds, uint64_t* max_node_tests) {
     if (!c) return PT_ERR_INVALID;
+    if (int rc = drain(c)) return rc;
     PT_HIP(c, hipSetDevice(c->device));
     const uint32_t n = (uint32_t)c->round_sizes.size();
     if (n_rounds) *n_rounds = n;
@@ -1010,6 +1158,7 @@ int pt_get_round_stats(pt_ctx* c, uint32_t* queue_sizes, uint32_t cap, uint32_t*
 
 int pt_set_option(pt_ctx* c, int option, uint64_t value) {
     if (!c) return PT_ERR_INVALID;
+    if (int rc = drain(c)) return rc;  // lanes in flight were set up for the old options
     switch (option) {
         case PT_OPT_BATCH_PATHS: c->opt_batch_slots = value ? std::max<uint64_t>(value, 64) : 0; return PT_OK;
         case PT_OPT_LANES: c->opt_lanes = std::min<uint64_t>(value, kMaxLanes); return PT_OK;
@@ -1045,15 +1194,59 @@ int pt_shard_map(uint32_t width, uint32_t height, uint32_t tile, uint32_t rank, 
     return PT_OK;
 }
 
+static bool tile_shard_ok(uint32_t width, uint32_t height, uint32_t tile, uint32_t rank, uint32_t nranks) {
+    return width != 0 && height != 0 && tile != 0 && tile % 8 == 0 && tile <= 1024 && nranks != 0 && rank < nranks;
+}
+
+int pt_shard_slab_floats(uint32_t width, uint32_t height, uint32_t tile, uint32_t rank, uint32_t nranks, uint64_t* n_floats) {
+    if (!n_floats || !tile_shard_ok(width, height, tile, rank, nranks)) return PT_ERR_INVALID;
+    PixelMap M{};
+    pixelmap_init(M, width, height, tile, rank, nranks);
+    *n_floats = (uint64_t)M.npix_pad * 3;
+    return PT_OK;
+}
+
+static int shard_copy(pt_ctx* c, const pt_shard* shard, float* slab, uint64_t n_floats, bool unpack, const char* who) {
+    if (!c) return PT_ERR_INVALID;
+    if (!c->have_cam) return c->fail(PT_ERR_STATE, std::string(who) + ": no camera");
+    if (!shard || shard->kind != PT_SHARD_TILES || !tile_shard_ok(c->cam.width, c->cam.height, shard->tile, shard->rank, shard->nranks))
+        return c->fail(PT_ERR_INVALID, std::string(who) + ": needs a valid PT_SHARD_TILES shard");
+    if (int rc = drain(c)) return rc;
+    PixelMap M{};
+    pixelmap_init(M, c->cam.width, c->cam.height, shard->tile, shard->rank, shard->nranks);
+    if (M.npix_pad == 0) return PT_OK;  // this rank owns no tile
+    if (!slab || n_floats < (uint64_t)M.npix_pad * 3) return c->fail(PT_ERR_INVALID, std::string(who) + ": slab too small (see pt_shard_slab_floats)");
+    PT_HIP(c, hipSetDevice(c->device));
+    launch_shard_copy(M, (float*)c->d_accum.p, slab, unpack, c->stream);
+    PT_HIP(c, hipGetLastError());
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+int pt_shard_pack(pt_ctx* c, const pt_shard* shard, float* slab_dev, uint64_t cap_floats) {
+    return shard_copy(c, shard, slab_dev, cap_floats, false, "pt_shard_pack");
+}
+
+int pt_shard_unpack(pt_ctx* c, const pt_shard* shard, const float* slab_dev, uint64_t n_floats) {
+    return shard_copy(c, shard, const_cast<float*>(slab_dev), n_floats, true, "pt_shard_unpack");
+}
+
 int pt_reset_counters(pt_ctx* c) {
     if (!c) return PT_ERR_INVALID;
+    if (int rc = drain(c)) return rc;
     PT_HIP(c, hipSetDevice(c->device));
     PT_HIP(c, hipMemset(c->d_counters.p, 0, CNT_N * sizeof(unsigned long long)));
     c->extend_launches = 0;
     c->tail_launches = 0;
-    c->tail_ms = 0;
-    c->extend_ms = 0;
     c->render_ms = 0;
+    pt_sched& S = *c->sched;
+    S.ext_iv.clear();
+    S.tail_iv.clear();
+    S.ext_sum = S.tail_sum = 0;
+    if (S.ev_epoch) {
+        (void)hipEventDestroy(S.ev_epoch);
+        S.ev_epoch = nullptr;
+    }
     return PT_OK;
 }
 

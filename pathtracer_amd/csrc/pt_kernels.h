@@ -95,6 +95,7 @@ void launch_path(int prim, bool nee, bool count, const DevScene& S, const DevCam
                  uint32_t sample_base, uint32_t depth, uint32_t k0, uint32_t k1, float4* out, uint32_t* cursor, const LaunchCfg& cfg,
                  unsigned long long* counters, hipStream_t st);
 void launch_accumulate(const PixelMap& M, const float4* out, uint32_t n_samples, bool pixel_major, float* accum, hipStream_t st);
+void launch_shard_copy(const PixelMap& M, float* accum, float* slab, bool unpack, hipStream_t st);
 void launch_resolve(const float* accum, uint32_t width, uint32_t height, float scale, uint8_t* rgb, uint64_t pitch, hipStream_t st);
 
 }  // namespace pt

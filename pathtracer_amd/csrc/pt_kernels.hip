@@ -844,7 +844,13 @@ __device__ __forceinline__ bool shade_core(const DevScene& S, PathVals& pv, cons
             const float nee_w = fmin_(1.0f - speculaty, 0.0f);
             if (S.n_lights != 0 && nee_w != 0.0f) {
                 const U4 rn = philox4x32_10(k0, k1, px.x, px.y, 1u + it, 1u);
-                const uint32_t lslot = S.lights[rn.v[0] % S.n_lights];
+                // BVH::random_light, bvh.rs:273-284: Range<usize>::ind_sample rejects draws at or above the largest
+                // multiple of the range and returns draw % range (rand 0.3.15); rejected draws are replaced by
+                // word 0 of the blocks (iteration, stream 2, 3, ...) of the counter-based generator
+                uint32_t pick = rn.v[0];
+                const uint32_t zone = 0xffffffffu - 0xffffffffu % S.n_lights;
+                for (uint32_t j = 0; pick >= zone; ++j) pick = philox4x32_10(k0, k1, px.x, px.y, 1u + it, 2u + j).v[0];
+                const uint32_t lslot = S.lights[pick % S.n_lights];
                 V3 Q, ln;
                 float larea, gdist = kInf;
                 bool lhit;
@@ -1402,6 +1408,24 @@ __global__ __launch_bounds__(64) void k_accumulate(PixelMap M, const float4* __r
     }
 }
 
+// Tile-sharded frames: a rank's tiles as one compact slab in the shard's own pixel order (tile by tile,
+// 8x8 blocks inside, padding pixels zero) — what is gathered over RCCL — and back into a frame.
+// unpack = 0: slab <- accum;  unpack = 1: accum <- slab (the un-swizzle on the gathering rank).
+__global__ __launch_bounds__(256) void k_shard_copy(PixelMap M, float* __restrict__ accum, float* __restrict__ slab, int unpack) {
+    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < M.npix_pad; idx += gridDim.x * blockDim.x) {
+        uint32_t x, y;
+        const bool valid = map_pixel(M, idx, &x, &y);
+        float* s = slab + (size_t)idx * 3;
+        if (!valid) {
+            if (!unpack) s[0] = s[1] = s[2] = 0.0f;
+            continue;
+        }
+        float* a = accum + ((size_t)y * M.width + x) * 3;
+        if (unpack) { a[0] = s[0]; a[1] = s[1]; a[2] = s[2]; }
+        else { s[0] = a[0]; s[1] = a[1]; s[2] = a[2]; }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_resolve(const float* __restrict__ accum, uint32_t width, uint32_t height, float scale,
                                                  uint8_t* __restrict__ rgb, uint64_t pitch) {
     const uint32_t n = width * height;
@@ -1522,6 +1546,10 @@ void launch_path(int prim, bool nee, bool count, const DevScene& S, const DevCam
 
 void launch_accumulate(const PixelMap& M, const float4* out, uint32_t n_samples, bool pixel_major, float* accum, hipStream_t st) {
     hipLaunchKernelGGL(k_accumulate, dim3(blocks_for(M.npix_pad, 64, 65536)), dim3(64), 0, st, M, out, n_samples, pixel_major ? 1 : 0, accum);
+}
+
+void launch_shard_copy(const PixelMap& M, float* accum, float* slab, bool unpack, hipStream_t st) {
+    hipLaunchKernelGGL(k_shard_copy, dim3(blocks_for(M.npix_pad, 256, 8192)), dim3(256), 0, st, M, accum, slab, unpack ? 1 : 0);
 }
 
 void launch_resolve(const float* accum, uint32_t width, uint32_t height, float scale, uint8_t* rgb, uint64_t pitch, hipStream_t st) {

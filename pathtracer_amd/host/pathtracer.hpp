@@ -110,6 +110,34 @@ inline Material backup_glass() { return Material::dielectric(1.0f, 1.5f, {0.01f,
 
 enum class Key { A, D, W, S, E, Q, R, F, Up, Down, Left, Right, H, P };
 
+// The arithmetic of Camera::handle_input, src/camera.rs:114-204, on (origin, target, depth): which keys
+// move what, in the reference's order and with its constants (A/D/R/F: origin and target +-0.1 along
+// right / up; W/S: origin only, +-0.1 along direction; E/Q: both, +-10 along direction; arrows: target
+// only, +-0.1 along up / right; H: depth 512 <-> 2).  `target` is first reset to origin + direction
+// (camera.rs:115) whether or not a key is down.  Returns `changed`; the caller then runs update().
+// Device-free, so it can be checked on the CPU.
+inline bool apply_input(const std::set<Key>& keys, const float direction[3], const float right[3], const float up[3], Vec3& origin,
+                        Vec3& target, uint32_t& depth) {
+    auto add = [](Vec3 a, float k, const float* v) { return Vec3{a[0] + k * v[0], a[1] + k * v[1], a[2] + k * v[2]}; };
+    target = add(origin, 1.0f, direction);
+    bool changed = false;
+    if (keys.count(Key::A)) { origin = add(origin, -0.1f, right); target = add(target, -0.1f, right); changed = true; }
+    if (keys.count(Key::D)) { origin = add(origin, 0.1f, right); target = add(target, 0.1f, right); changed = true; }
+    if (keys.count(Key::W)) { origin = add(origin, 0.1f, direction); changed = true; }
+    if (keys.count(Key::E)) { origin = add(origin, 10.0f, direction); target = add(target, 10.0f, direction); changed = true; }
+    if (keys.count(Key::Q)) { origin = add(origin, -10.0f, direction); target = add(target, -10.0f, direction); changed = true; }
+    if (keys.count(Key::H)) { depth = depth == 512 ? 2 : 512; changed = true; }  // field otherwise unused, as in the reference
+    if (keys.count(Key::P)) std::printf("origin: (%g, %g, %g), direction: (%g, %g, %g)\n", origin[0], origin[1], origin[2], direction[0], direction[1], direction[2]);
+    if (keys.count(Key::S)) { origin = add(origin, -0.1f, direction); changed = true; }
+    if (keys.count(Key::R)) { origin = add(origin, 0.1f, up); target = add(target, 0.1f, up); changed = true; }
+    if (keys.count(Key::F)) { origin = add(origin, -0.1f, up); target = add(target, -0.1f, up); changed = true; }
+    if (keys.count(Key::Up)) { target = add(target, -0.1f, up); changed = true; }
+    if (keys.count(Key::Down)) { target = add(target, 0.1f, up); changed = true; }
+    if (keys.count(Key::Left)) { target = add(target, -0.1f, right); changed = true; }
+    if (keys.count(Key::Right)) { target = add(target, 0.1f, right); changed = true; }
+    return changed;
+}
+
 namespace detail {
 inline void check(pt_ctx* c, int rc, const char* what) {
     if (rc != PT_OK) throw Error(rc, std::string(what) + ": " + (c ? pt_last_error(c) : pt_strerror(rc)));
@@ -180,32 +208,24 @@ public:
     // Camera::handle_input, src/camera.rs:114-212.  Returns true when the camera moved (the
     // accumulation is then reset, as main.rs:137-142 does).
     bool handle_input(const std::set<Key>& keys) {
-        const pt_camera_state& s = state_;
-        auto add = [](Vec3 a, float k, const float* v) { return Vec3{a[0] + k * v[0], a[1] + k * v[1], a[2] + k * v[2]}; };
-        target_ = add(origin_, 1.0f, s.direction);
-        bool changed = false;
-        if (keys.count(Key::A)) { origin_ = add(origin_, -0.1f, s.right); target_ = add(target_, -0.1f, s.right); changed = true; }
-        if (keys.count(Key::D)) { origin_ = add(origin_, 0.1f, s.right); target_ = add(target_, 0.1f, s.right); changed = true; }
-        if (keys.count(Key::W)) { origin_ = add(origin_, 0.1f, s.direction); changed = true; }
-        if (keys.count(Key::E)) { origin_ = add(origin_, 10.0f, s.direction); target_ = add(target_, 10.0f, s.direction); changed = true; }
-        if (keys.count(Key::Q)) { origin_ = add(origin_, -10.0f, s.direction); target_ = add(target_, -10.0f, s.direction); changed = true; }
-        if (keys.count(Key::H)) { depth_ = depth_ == 512 ? 2 : 512; changed = true; }  // field otherwise unused, as in the reference
-        if (keys.count(Key::P)) std::printf("origin: (%g, %g, %g), direction: (%g, %g, %g)\n", origin_[0], origin_[1], origin_[2], s.direction[0], s.direction[1], s.direction[2]);
-        if (keys.count(Key::S)) { origin_ = add(origin_, -0.1f, s.direction); changed = true; }
-        if (keys.count(Key::R)) { origin_ = add(origin_, 0.1f, s.up); target_ = add(target_, 0.1f, s.up); changed = true; }
-        if (keys.count(Key::F)) { origin_ = add(origin_, -0.1f, s.up); target_ = add(target_, -0.1f, s.up); changed = true; }
-        if (keys.count(Key::Up)) { target_ = add(target_, -0.1f, s.up); changed = true; }
-        if (keys.count(Key::Down)) { target_ = add(target_, 0.1f, s.up); changed = true; }
-        if (keys.count(Key::Left)) { target_ = add(target_, -0.1f, s.right); changed = true; }
-        if (keys.count(Key::Right)) { target_ = add(target_, 0.1f, s.right); changed = true; }
+        const bool changed = apply_input(keys, state_.direction, state_.right, state_.up, origin_, target_, depth_);
         if (changed) update();
         return changed;
     }
+    Vec3 origin() const { return origin_; }
+    Vec3 target() const { return target_; }
+    uint32_t depth() const { return depth_; }
 
     // the frame loop body, src/main.rs:143-170, for `spp` frames of one sample each
     void render(uint32_t spp = 1, uint32_t max_depth = 32, uint64_t seed = 0) {
         detail::check(ctx_, pt_render(ctx_, spp, max_depth, seed, nullptr, 0), "pt_render");
     }
+    // the same frame queued without waiting (pt_render_async): consecutive frames overlap on the device,
+    // the sums stay in frame order; rgb24() / accum() / wait() wait for everything queued
+    void render_async(uint32_t spp = 1, uint32_t max_depth = 32, uint64_t seed = 0) {
+        detail::check(ctx_, pt_render_async(ctx_, spp, max_depth, seed, nullptr, 0), "pt_render_async");
+    }
+    void wait() { detail::check(ctx_, pt_wait(ctx_), "pt_wait"); }
     // vec_to_rgb(scale * accum) into an RGB24 buffer with SDL-style pitch, src/main.rs:160-164
     void rgb24(uint8_t* buffer, size_t pitch) { detail::check(ctx_, pt_read_rgb8(ctx_, buffer, pitch), "pt_read_rgb8"); }
     float accum(std::vector<float>& rgb) {

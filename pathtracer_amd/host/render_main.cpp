@@ -5,6 +5,13 @@
 // --obj        Scene::scene(path) of src/scene.rs:35: load_mesh + light + floor (needs vertex normals)
 // --save-accum / --resume   fp32 accumulation dump and restart (W, H, spp header + W*H*3 floats)
 // --dump-mesh  write what load_mesh returned (24 floats per triangle) and exit; needs no GPU
+// --keys "W,A;D;Up,Left"   Camera::handle_input once per ';'-separated key set before rendering; prints the pose
+//              after each step as hex float bits (changed, origin, target, direction, right, up, p1, p2, p3, focal distance)
+// --input-check  device-free check of the key arithmetic: reads lines "<15 hex words: origin target direction right up>
+//              <depth> <keys>" from stdin, prints "<changed> <6 hex words: origin target> <depth>" per line
+// --async      queue the frames with render_async and wait once at the end (frames overlap on the device)
+#include <iostream>
+#include <sstream>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -51,7 +58,64 @@ static std::vector<Triangle> cube_mesh(Material m) {
 
 struct AccumFile {
     std::string save, resume;
+    bool async = false;
 };
+
+static bool parse_keys(const std::string& list, std::set<Key>& out) {
+    static const std::pair<const char*, Key> names[] = {{"A", Key::A}, {"D", Key::D}, {"W", Key::W}, {"S", Key::S}, {"E", Key::E},
+                                                        {"Q", Key::Q}, {"R", Key::R}, {"F", Key::F}, {"Up", Key::Up}, {"Down", Key::Down},
+                                                        {"Left", Key::Left}, {"Right", Key::Right}, {"H", Key::H}, {"P", Key::P}};
+    std::stringstream ss(list);
+    std::string k;
+    while (std::getline(ss, k, ',')) {
+        if (k.empty() || k == "-") continue;
+        bool found = false;
+        for (const auto& n : names)
+            if (k == n.first) { out.insert(n.second); found = true; }
+        if (!found) return false;
+    }
+    return true;
+}
+static uint32_t bits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+static float from_bits(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+
+static int input_check() {
+    std::string line;
+    while (std::getline(std::cin, line)) {
+        std::stringstream ss(line);
+        float v[15];
+        for (float& x : v) { uint32_t u; ss >> std::hex >> u; x = from_bits(u); }
+        uint32_t depth;
+        std::string keys;
+        ss >> std::dec >> depth >> keys;
+        std::set<Key> ks;
+        if (!ss || !parse_keys(keys, ks)) { std::fprintf(stderr, "bad line: %s\n", line.c_str()); return 2; }
+        Vec3 origin{v[0], v[1], v[2]}, target{v[3], v[4], v[5]};
+        const bool changed = apply_input(ks, v + 6, v + 9, v + 12, origin, target, depth);
+        std::printf("%d %08x %08x %08x %08x %08x %08x %u\n", changed ? 1 : 0, bits(origin[0]), bits(origin[1]), bits(origin[2]), bits(target[0]),
+                    bits(target[1]), bits(target[2]), depth);
+    }
+    return 0;
+}
+
+template <class T>
+static bool play_keys(Camera<T>& camera, const std::string& steps) {
+    std::stringstream ss(steps);
+    std::string step;
+    while (std::getline(ss, step, ';')) {
+        std::set<Key> ks;
+        if (!parse_keys(step, ks)) return false;
+        const bool changed = camera.handle_input(ks);
+        const pt_camera_state& s = camera.state();
+        const Vec3 o = camera.origin(), t = camera.target();
+        std::printf("pose %d", changed ? 1 : 0);
+        for (float x : {o[0], o[1], o[2], t[0], t[1], t[2]}) std::printf(" %08x", bits(x));
+        for (const float* p : {s.direction, s.right, s.up, s.p1, s.p2, s.p3})
+            for (int a = 0; a < 3; ++a) std::printf(" %08x", bits(p[a]));
+        std::printf(" %08x %u\n", bits(s.focal_distance), camera.depth());
+    }
+    return true;
+}
 
 template <class T>
 static int run(Camera<T>& camera, uint32_t W, uint32_t H, int frames, int spp, const std::string& out, const AccumFile& af) {
@@ -73,9 +137,14 @@ static int run(Camera<T>& camera, uint32_t W, uint32_t H, int frames, int spp, c
     }
     auto t0 = std::chrono::steady_clock::now();
     for (int f = 0; f < frames; ++f) {
-        camera.render(spp, 32, 2026);   // spp += 1 per frame in the reference, main.rs:143
-        camera.rgb24(fb.data(), (size_t)W * 3);
+        if (af.async) {
+            camera.render_async(spp, 32, 2026);  // queued: the frame is shown when it has been added
+        } else {
+            camera.render(spp, 32, 2026);   // spp += 1 per frame in the reference, main.rs:143
+            camera.rgb24(fb.data(), (size_t)W * 3);
+        }
     }
+    if (af.async) camera.rgb24(fb.data(), (size_t)W * 3);  // waits for every queued frame
     double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     pt_counters c = camera.counters();
     std::printf("%d frames x %d spp: %.1f ms/frame, %.1f Mrays/s, %.1f Mpaths/s, focal distance %g\n", frames, spp, dt * 1e3 / frames,
@@ -102,7 +171,7 @@ int main(int argc, char** argv) {
     uint32_t W = 800, H = 600;  // main.rs:77-78
     int frames = 16, spp = 1;
     bool spheres = false;
-    std::string out = "frame.ppm", sky_path, obj_path, dump_path;
+    std::string out = "frame.ppm", sky_path, obj_path, dump_path, keys;
     AccumFile af;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -117,6 +186,9 @@ int main(int argc, char** argv) {
         else if (a == "--dump-mesh" && i + 1 < argc) dump_path = argv[++i];
         else if (a == "--save-accum" && i + 1 < argc) af.save = argv[++i];
         else if (a == "--resume" && i + 1 < argc) af.resume = argv[++i];
+        else if (a == "--keys" && i + 1 < argc) keys = argv[++i];
+        else if (a == "--async") af.async = true;
+        else if (a == "--input-check") return input_check();
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
     try {
@@ -139,13 +211,16 @@ int main(int argc, char** argv) {
         if (spheres) {
             Camera<Sphere> camera(W, H, Scene<Sphere>::default_scene(std::move(sky)));
             camera.look_at({0.0f, 0.2f, 1.0f}, {0.0f, -0.2f, -2.0f});  // the default pose looks away from the spheres
+            if (!play_keys(camera, keys)) return 2;
             return run(camera, W, H, frames, spp, out, af);
         }
         if (!obj_path.empty()) {
             Camera<Triangle> camera(W, H, Scene<Triangle>::scene(std::move(mesh), std::move(sky)));  // floor speculaty 0.5, scene.rs:63
+            if (!play_keys(camera, keys)) return 2;
             return run(camera, W, H, frames, spp, out, af);
         }
         Camera<Triangle> camera(W, H, Scene<Triangle>::scene(cube_mesh(Material::dielectric(1.0f, 1.5f, {0.01f, 0.9f, 0.01f})), std::move(sky), 0.0f));
+        if (!play_keys(camera, keys)) return 2;
         return run(camera, W, H, frames, spp, out, af);
     } catch (const Error& e) {
         std::fprintf(stderr, "error %d: %s\n", e.status, e.what());

@@ -36,8 +36,8 @@ OPT_BATCH_PATHS, OPT_LANES, OPT_TAIL_MIN_PATHS, OPT_TAIL_FRACTION, OPT_TAIL_STRE
 
 EXPORTS = [
     "pt_strerror", "pt_last_error", "pt_create", "pt_destroy", "pt_set_triangles", "pt_set_spheres", "pt_set_materials",
-    "pt_set_sky", "pt_build", "pt_set_bvh", "pt_bvh_build", "pt_get_bvh_sizes", "pt_get_bvh", "pt_set_camera", "pt_get_camera", "pt_generate", "pt_render",
-    "pt_shard_map", "pt_reset_accum", "pt_read_accum", "pt_write_accum", "pt_read_rgb8", "pt_accum_device_ptr", "pt_add_external_samples", "pt_trace",
+    "pt_set_sky", "pt_build", "pt_set_bvh", "pt_bvh_build", "pt_get_bvh_sizes", "pt_get_bvh", "pt_set_camera", "pt_get_camera", "pt_generate", "pt_render", "pt_render_async", "pt_wait",
+    "pt_shard_map", "pt_shard_slab_floats", "pt_shard_pack", "pt_shard_unpack", "pt_reset_accum", "pt_read_accum", "pt_write_accum", "pt_read_rgb8", "pt_accum_device_ptr", "pt_add_external_samples", "pt_trace",
     "pt_sample_skybox", "pt_set_option", "pt_get_counters", "pt_get_round_stats", "pt_reset_counters",
 ]
 
@@ -65,7 +65,7 @@ class Counters(C.Structure):
                 ("node_tests", C.c_uint64), ("prim_tests", C.c_uint64), ("extend_launches", C.c_uint64),
                 ("extend_ms", C.c_double), ("render_ms", C.c_double), ("tail_rays", C.c_uint64),
                 ("tail_node_tests", C.c_uint64), ("tail_prim_tests", C.c_uint64), ("tail_launches", C.c_uint64),
-                ("tail_ms", C.c_double)]
+                ("tail_ms", C.c_double), ("extend_ms_sum", C.c_double), ("tail_ms_sum", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -137,6 +137,16 @@ def shard_map(width, height, tile=8, rank=0, nranks=1):
     lib.pt_shard_map(C.c_uint32(width), C.c_uint32(height), C.c_uint32(tile), C.c_uint32(rank), C.c_uint32(nranks),
                      _ptr(xy), C.c_uint64(n.value), C.byref(n))
     return xy
+
+
+def shard_slab_floats(width, height, tile, rank, nranks):
+    """floats in the compact slab of a tile shard (pt_shard_slab_floats, no device)."""
+    lib = load()
+    n = C.c_uint64()
+    rc = lib.pt_shard_slab_floats(C.c_uint32(width), C.c_uint32(height), C.c_uint32(tile), C.c_uint32(rank), C.c_uint32(nranks), C.byref(n))
+    if rc != PT_OK:
+        raise PtError(rc, lib.pt_strerror(rc).decode())
+    return n.value
 
 
 class PathTracer:
@@ -242,6 +252,14 @@ class PathTracer:
         sp = C.byref(shard) if shard is not None else None
         self._ck(self.l.pt_render(self.h, C.c_uint32(spp), C.c_uint32(max_depth), C.c_uint64(seed), sp, C.c_uint32(flags)))
 
+    def render_async(self, spp, max_depth=32, seed=0, shard=None, flags=0):
+        """Queue a render call and return; calls overlap on the device, sums stay in call order (pt_render_async)."""
+        sp = C.byref(shard) if shard is not None else None
+        self._ck(self.l.pt_render_async(self.h, C.c_uint32(spp), C.c_uint32(max_depth), C.c_uint64(seed), sp, C.c_uint32(flags)))
+
+    def wait(self):
+        self._ck(self.l.pt_wait(self.h))
+
     def reset_accum(self):
         self._ck(self.l.pt_reset_accum(self.h))
 
@@ -267,6 +285,14 @@ class PathTracer:
         p, n = C.c_void_p(), C.c_uint64()
         self._ck(self.l.pt_accum_device_ptr(self.h, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def shard_pack(self, shard, slab_ptr, cap_floats):
+        """accumulator pixels of a tile shard -> compact slab in DEVICE memory (pt_shard_pack)."""
+        self._ck(self.l.pt_shard_pack(self.h, C.byref(shard), C.c_void_p(slab_ptr), C.c_uint64(cap_floats)))
+
+    def shard_unpack(self, shard, slab_ptr, n_floats):
+        """compact slab in DEVICE memory -> the shard's pixels of the accumulator (pt_shard_unpack)."""
+        self._ck(self.l.pt_shard_unpack(self.h, C.byref(shard), C.c_void_p(slab_ptr), C.c_uint64(n_floats)))
 
     def add_external_samples(self, spp):
         self._ck(self.l.pt_add_external_samples(self.h, C.c_float(spp)))

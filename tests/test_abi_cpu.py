@@ -31,7 +31,7 @@ def test_struct_layouts_match_header():
     assert scenes.MATERIAL_DTYPE.itemsize == 24
     assert C.sizeof(ptcore.CameraState) == 8 * 12 + 16
     assert C.sizeof(ptcore.Shard) == 20
-    assert C.sizeof(ptcore.Counters) == 104
+    assert C.sizeof(ptcore.Counters) == 120
 
 
 def test_no_device_is_an_error_not_a_fallback():

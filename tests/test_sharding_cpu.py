@@ -39,8 +39,22 @@ def _worker(rank, world, port, out_path):
     tiles = np.zeros((H, W, 3), np.float32)
     for s in range(SPP):
         tiles[xy[:, 1], xy[:, 0]] += o.sample_pixels(xy, s, DEPTH, SEED, nee_mode=1)
-    t = torch.from_numpy(tiles)
+    t = torch.from_numpy(tiles.copy())
     dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+
+    # the same shards combined the C4 way (pathtracer_amd/dist.py): every rank packs its own tiles into a
+    # compact slab (numpy stands in for pt_shard_pack), ONE gather of equal slabs, rank 0 un-swizzles
+    from pathtracer_amd import dist as ptdist
+    n0 = ptcore.shard_slab_floats(W, H, TILE, 0, world)
+    pix = ptdist.slab_pixel_index(W, H, TILE, rank, world)
+    slab = np.zeros((n0 // 3, 3), np.float32)
+    slab[:len(pix)][pix >= 0] = tiles.reshape(-1, 3)[pix[pix >= 0]]
+    parts = ptdist.gather_slabs(torch.from_numpy(slab), dst=0)
+    gathered = np.zeros((H * W, 3), np.float32)
+    if rank == 0:
+        for r, part in enumerate(parts):
+            pr = ptdist.slab_pixel_index(W, H, TILE, r, world)
+            gathered[pr[pr >= 0]] = part.numpy()[:len(pr)][pr >= 0]
 
     # sample sharding: global sample indices [rank * SPP/world, (rank+1) * SPP/world)
     per = SPP // world
@@ -52,7 +66,7 @@ def _worker(rank, world, port, out_path):
     if rank == 0:
         o.reset_accum()
         o.render(SPP, DEPTH, SEED, nthreads=2, nee_mode=1)
-        np.savez(out_path, tiles=t.numpy(), samples=s_acc.numpy(), full=o.read_accum()[0])
+        np.savez(out_path, tiles=t.numpy(), gathered=gathered.reshape(H, W, 3), samples=s_acc.numpy(), full=o.read_accum()[0])
     dist.barrier()
     dist.destroy_process_group()
 
@@ -79,6 +93,21 @@ def test_shard_map_partitions_the_frame():
         ptcore.shard_map(16, 16, 12, 0, 1)  # tile must be a multiple of 8
 
 
+def test_slab_order_is_the_device_order():
+    """dist.slab_pixel_index (numpy) restates the order pt_shard_pack writes a slab in; its valid entries must be
+    exactly pt_shard_map's pixels in the same order, and pt_shard_slab_floats must give its length."""
+    sys.path.insert(0, ROOT)
+    from pathtracer_amd import dist as ptdist
+    from pathtracer_amd import ptcore
+    for (w, h, tile, n) in [(48, 40, 16, 2), (100, 60, 16, 3), (33, 17, 8, 4), (3840, 2160, 64, 8), (70, 50, 64, 4)]:
+        for r in range(n):
+            pix = ptdist.slab_pixel_index(w, h, tile, r, n)
+            assert len(pix) * 3 == ptcore.shard_slab_floats(w, h, tile, r, n)
+            xy = ptcore.shard_map(w, h, tile, r, n).astype(np.int64)
+            assert np.array_equal(pix[pix >= 0], xy[:, 1] * w + xy[:, 0])
+        assert ptcore.shard_slab_floats(w, h, tile, 0, n) >= max(ptcore.shard_slab_floats(w, h, tile, r, n) for r in range(n))
+
+
 def test_two_rank_gloo_shards_reassemble(tmp_path):
     out = str(tmp_path / "res.npz")
     port = _free_port()
@@ -86,5 +115,6 @@ def test_two_rank_gloo_shards_reassemble(tmp_path):
     r = np.load(out)
     # disjoint pixel sets: the reduce adds zeros, so the tile-sharded frame is bit-identical
     assert r["tiles"].tobytes() == r["full"].tobytes()
+    assert r["gathered"].tobytes() == r["full"].tobytes()  # gather of compact slabs + un-swizzle: the same frame
     # sample shards are summed in a different order than the single frame loop: fp32 tolerance
     np.testing.assert_allclose(r["samples"], r["full"], rtol=1e-6, atol=1e-7)
