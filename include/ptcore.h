@@ -217,6 +217,14 @@ int pt_shard_unpack(pt_ctx *ctx, const pt_shard *shard, const float *slab_dev, u
 
 /* BVH::intersect_closest / intersect_any (src/bvh.rs:180-271) over a batch of rays. */
 int pt_trace(pt_ctx *ctx, const pt_ray *rays, uint64_t n, int any_hit, pt_hit *hits);
+/* pt_trace without any allocation.  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot
+ * call hipMalloc — code under HIP graph capture, tight serving loops, harnesses that forbid allocation.
+ * Same arguments, results and counters as pt_trace; the device copies of rays / hits and the overflow of the
+ * per-lane traversal stacks live in a static device array (8.6 MiB per GPU, held until the process ends)
+ * instead of per-call buffers.  Limits: n <= 16384 rays per call and a tree of at most 76 levels
+ * (PT_ERR_LIMIT otherwise; pt_trace has neither limit).  All contexts on one GPU share that array:
+ * calls that overlap on one GPU race — serialise them. */
+int pt_trace_noalloc(pt_ctx *ctx, const pt_ray *rays, uint64_t n, int any_hit, pt_hit *hits);
 /* Scene::sample_skybox (src/scene.rs:162-169) for n directions (n x 3 floats) -> n x 3 floats. */
 int pt_sample_skybox(pt_ctx *ctx, const float *dirs, uint64_t n, float *rgb);
 

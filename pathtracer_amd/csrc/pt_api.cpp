@@ -42,6 +42,16 @@ constexpr uint32_t kMaxLanes = 8;              // batches in flight (one HIP str
 constexpr uint64_t kTailMinPaths = 65536;      // hand a batch to the fused tail kernel below this many live paths ...
 constexpr uint64_t kTailFraction = 16;         // ... or below 1/16 of the batch
 
+// ---- pt_trace_noalloc: everything pt_trace allocates per call lives in one static device array instead.
+// Layout: [rays: kNoAllocMaxRays x pt_ray][hits: kNoAllocMaxRays x pt_hit][stack spill: levels x lanes x 8 B].
+constexpr uint32_t kNoAllocMaxRays = 16384;      // rays per call (= lanes of the launch: one ray per lane)
+constexpr uint32_t kNoAllocSpillLevels = 64;     // stack levels beyond the LDS part: trees up to kLdsStack + 64 levels deep
+constexpr size_t kScratchRays = 0;
+constexpr size_t kScratchHits = kScratchRays + (size_t)kNoAllocMaxRays * sizeof(pt_ray);
+constexpr size_t kScratchSpill = (kScratchHits + (size_t)kNoAllocMaxRays * sizeof(pt_hit) + 255) & ~(size_t)255;
+constexpr size_t kScratchBytes = kScratchSpill + (size_t)kNoAllocSpillLevels * kNoAllocMaxRays * sizeof(unsigned long long);  // 8.6 MiB
+constexpr int kMaxDevices = 64;
+
 // One batch in flight.
 struct RenderJob;
 struct RenderLane {
@@ -75,6 +85,27 @@ struct RenderJob {
 };
 
 }  // namespace
+
+// The scratch memory of pt_trace_noalloc.  Every GPU the library runs on holds its own copy at its own
+// address for the life of the process.  In host code this name is only a handle for
+// hipGetSymbolAddress: the device address is resolved once per device in pt_create (g_scratch_ptr)
+// and only that pointer is ever handed to kernels or copies.
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+static unsigned char* g_scratch_ptr[kMaxDevices] = {};
+
+// with `device` current: the address of this device's copy of `scratch`
+static hipError_t resolve_scratch(int device, unsigned char** out) {
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    if (!g_scratch_ptr[device]) {
+        unsigned char* p = nullptr;
+        hipError_t e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        g_scratch_ptr[device] = p;
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
 
 struct pt_sched {
     std::deque<RenderJob> jobs;   // submitted, not yet retired (front = oldest)
@@ -119,6 +150,7 @@ struct pt_ctx {
     LaunchCfg cfg{};          // grid geometry; every lane has its own spill area
     size_t spill_bytes = 16;
     DevBuf d_spill;           // spill area of the seams (pt_trace, focus)
+    unsigned char* scratch_ptr = nullptr;  // this device's copy of the static scratch array (pt_trace_noalloc)
     RenderLane lanes[kMaxLanes];
     hipStream_t tail_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t bulk_stream[kMaxLanes] = {};  // the round kernels of lane i run on bulk_stream[i % opt_bulk_streams]  // high priority: the few latency-bound tail waves go first
@@ -201,6 +233,10 @@ int pt_create(int device, pt_ctx** out) {
                 pt_destroy(c);
                 return PT_ERR_HIP;
             }
+    }
+    if (resolve_scratch(device, &c->scratch_ptr) != hipSuccess) {  // hipSetDevice(device) happened above
+        delete c;
+        return PT_ERR_HIP;
     }
     c->sched = new pt_sched();
     if (hipStreamCreateWithFlags(&c->acc_stream, hipStreamNonBlocking) != hipSuccess) {
@@ -590,6 +626,39 @@ int pt_trace(pt_ctx* c, const pt_ray* rays, uint64_t n, int any_hit, pt_hit* hit
     dr.release();
     dh.release();
     if (e != hipSuccess) return c->fail(PT_ERR_HIP, std::string("pt_trace: ") + hipGetErrorString(e));
+    return PT_OK;
+}
+
+// pt_trace for callers that may not allocate: rays, hits and the stack-spill area live in this
+// device's copy of the static `scratch` array (through the pointer resolved in pt_create, never
+// through the array's name).  No hipMalloc / hipFree here or below.  Nothing in the scratch has to
+// start at zero: staged rays and hits are written before they are read, and a stack level is
+// always pushed before it is popped.  All contexts of one GPU share the array, so calls that
+// overlap on one GPU race.
+int pt_trace_noalloc(pt_ctx* c, const pt_ray* rays, uint64_t n, int any_hit, pt_hit* hits) {
+    if (!c) return PT_ERR_INVALID;
+    if (!c->built) return c->fail(PT_ERR_STATE, "pt_trace_noalloc: call pt_build first");
+    if (n == 0) return PT_OK;
+    if (!rays || !hits) return c->fail(PT_ERR_INVALID, "pt_trace_noalloc: null pointer");
+    if (n > kNoAllocMaxRays)
+        return c->fail(PT_ERR_LIMIT, "pt_trace_noalloc: more than 16384 rays in one call (the static scratch holds no more): split the batch or use pt_trace");
+    const uint32_t extra = c->ds.stack_cap > (uint32_t)kLdsStack ? c->ds.stack_cap - kLdsStack : 0;
+    if (extra > kNoAllocSpillLevels)
+        return c->fail(PT_ERR_LIMIT, "pt_trace_noalloc: the tree is deeper than 76 levels (the static scratch holds 64 spill levels): use pt_trace");
+    if (!c->scratch_ptr) return c->fail(PT_ERR_STATE, "pt_trace_noalloc: scratch not resolved");
+    PT_HIP(c, hipSetDevice(c->device));
+    unsigned char* base = c->scratch_ptr;
+    pt_ray* d_rays = (pt_ray*)(base + kScratchRays);
+    pt_hit* d_hits = (pt_hit*)(base + kScratchHits);
+    LaunchCfg cfg;
+    cfg.grid = kNoAllocMaxRays / kTraceBlock;  // one ray per lane at most: a lane's spill column is its global thread id
+    cfg.spill = (unsigned long long*)(base + kScratchSpill);
+    cfg.spill_stride = kNoAllocMaxRays;
+    PT_HIP(c, hipMemcpyAsync(d_rays, rays, n * sizeof(pt_ray), hipMemcpyHostToDevice, c->stream));
+    launch_trace(c->prim_kind, any_hit != 0, true, c->ds, d_rays, n, d_hits, cfg, (unsigned long long*)c->d_counters.p, c->stream);
+    PT_HIP(c, hipGetLastError());
+    PT_HIP(c, hipMemcpyAsync(hits, d_hits, n * sizeof(pt_hit), hipMemcpyDeviceToHost, c->stream));
+    PT_HIP(c, hipStreamSynchronize(c->stream));
     return PT_OK;
 }
 

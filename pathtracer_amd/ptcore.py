@@ -37,7 +37,7 @@ OPT_BATCH_PATHS, OPT_LANES, OPT_TAIL_MIN_PATHS, OPT_TAIL_FRACTION, OPT_TAIL_STRE
 EXPORTS = [
     "pt_strerror", "pt_last_error", "pt_create", "pt_destroy", "pt_set_triangles", "pt_set_spheres", "pt_set_materials",
     "pt_set_sky", "pt_build", "pt_set_bvh", "pt_bvh_build", "pt_get_bvh_sizes", "pt_get_bvh", "pt_set_camera", "pt_get_camera", "pt_generate", "pt_render", "pt_render_async", "pt_wait",
-    "pt_shard_map", "pt_shard_slab_floats", "pt_shard_pack", "pt_shard_unpack", "pt_reset_accum", "pt_read_accum", "pt_write_accum", "pt_read_rgb8", "pt_accum_device_ptr", "pt_add_external_samples", "pt_trace",
+    "pt_shard_map", "pt_shard_slab_floats", "pt_shard_pack", "pt_shard_unpack", "pt_reset_accum", "pt_read_accum", "pt_write_accum", "pt_read_rgb8", "pt_accum_device_ptr", "pt_add_external_samples", "pt_trace", "pt_trace_noalloc",
     "pt_sample_skybox", "pt_set_option", "pt_get_counters", "pt_get_round_stats", "pt_reset_counters",
 ]
 
@@ -302,6 +302,13 @@ class PathTracer:
         rays = as_rays(rays)
         hits = np.zeros(len(rays), dtype=HIT_DTYPE)
         self._ck(self.l.pt_trace(self.h, _ptr(rays), C.c_uint64(len(rays)), C.c_int(1 if any_hit else 0), _ptr(hits)))
+        return hits
+
+    def trace_noalloc(self, rays, any_hit=False):
+        """pt_trace_noalloc: same results as trace(), no device allocation (<= 16384 rays per call)."""
+        rays = as_rays(rays)
+        hits = np.zeros(len(rays), dtype=HIT_DTYPE)
+        self._ck(self.l.pt_trace_noalloc(self.h, _ptr(rays), C.c_uint64(len(rays)), C.c_int(1 if any_hit else 0), _ptr(hits)))
         return hits
 
     def sample_skybox(self, dirs):
