@@ -1,57 +1,100 @@
 """bench.py — Mrays/s of the path-tracing hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload C3] [--spp 256] [--shard samples|tiles]
 
-A "step" is one pass of the hot path over one batch: `--spp` samples per pixel of the named
-workload (default C3: 871 414-triangle glass statue on a diffuse floor, 1920x1080, depth 32)
-rendered by pt_render (default: the persistent path kernel k_path — raygen, traversal, shading
-and the bounce loop in one launch per batch — then accumulate; `--mode wavefront` selects the
-raygen -> extend/shade rounds -> fused tail variant).  Scene, BVH and sky are
-resident in HBM before the timed region.  For N > 1 (one process per GPU, torch.distributed over
-RCCL) every rank renders its own sample indices of the whole frame (sample sharding, weak
-scaling: per-GPU work is fixed) and the partial sums are combined by ONE reduce to rank 0 at
-readout, inside the timed region.  value = rays traced by all ranks / max-over-ranks time.
+A "step" is one pass of the hot path over one batch: `--spp` samples per pixel of the named workload
+(default C3: 871 414-triangle glass statue on a diffuse floor, 1920x1080, depth 32) rendered by
+pt_render (default: the persistent path kernel k_path — raygen, traversal, shading and the bounce loop
+in one launch per batch — then accumulate; `--mode wavefront` selects raygen -> extend/shade rounds ->
+fused tail).  Scene, BVH and sky are resident in HBM before the timed region.
+
+N > 1: one process per GPU over RCCL (torch.distributed, backend nccl).  Started by the driver through
+torch.distributed.run, or — when RANK is not in the environment — by this script itself, which then
+launches N ranks before anything touches a GPU and exits with their status.
+  --shard samples (default)  every rank renders its own sample indices of the whole frame; ONE
+                             reduce to rank 0 at readout, inside the timed region; weak scaling.
+  --shard tiles              BASELINE C4's split: rank r renders the 64x64 tiles t with t % N == r; ONE
+                             gather of compact tile slabs to rank 0 + un-swizzle; strong scaling.
+value = rays traced by all ranks / max-over-ranks time.
 
 Extra objects on the JSON line:
-  roofline     the dominant kernel (k_path; k_extend in wavefront mode) against the HBM roof:
-               algorithmic bytes B_ray = 32 * node_tests + 36 * prim_tests + 28 + 12 per ray plus,
-               for k_path, B_shade = 100 B per bounce + 36 B per path (the counts
-               come from an instrumented, untimed replay of the very same steps) divided by the
-               HIP-event time of that kernel's launches in the timed region.  `traffic` is the
-               L2-miss traffic per launch from rocprofv3 PMC passes (profiles/r1_traffic.json).
-  cpu_baseline the CPU oracle (a C++ restatement of the reference, kind "port") in the
-               reference's threading mode on this box's host cores, on a bounded sample.
+  roofline     the dominant kernel (k_path) against the roof that binds it.  SURVEY 8(d)'s algorithmic
+               bytes (B_ray = 32 * node_tests + 36 * prim_tests + 28 + 12 per ray, + 100 B per bounce + 36 B per
+               path; counts from an instrumented, untimed replay of the very same steps) are reported under
+               `algorithmic` — they are served by L1 / L2 / Infinity Cache, so against the HBM peak they can
+               exceed 1 and are NOT the headline.  The headline fraction is the highest roof fraction that can
+               bind: `hbm` = fabric traffic per launch from rocprofv3 FETCH_SIZE / WRITE_SIZE passes
+               (profiles/r2_pmc.json, corrected as profiles/README.md states) / live kernel time / 8 TB/s, or
+               `valu` = VALU wave-instructions per launch (SQ_INSTS_VALU pass) / live kernel time / the issue
+               peak (1024 SIMDs x 2.4 GHz / 4 cycles); `lane_util` says how full those instructions were.
+               Kernel time is measured live with HIP events on the launching stream.
+  cpu_baseline the CPU oracle (a C++ restatement of the reference, kind "port") in the reference's
+               threading mode on this box's host cores, on a bounded sample of the same workload.
+  cpu_configs  BASELINE configs[0] (C1: sphere scene 512x512, 1 spp per frame) on the CPU path, with the
+               GPU's rate on the same frames beside it.
+  spp_sweep    Mrays/s at 1 / 8 / 64 samples per call, calls queued with pt_render_async (and 1 spp blocking).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402  (imported before libptcore so both share one HIP runtime)
-import torch.distributed as dist  # noqa: E402
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+VALU_PEAK_GWIPS = 1024 * 2.4 / 4  # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz = 614.4 G wave-inst/s
+PMC_FILE = os.path.join(ROOT, "profiles", "r2_pmc.json")
 
-from pathtracer_amd import ptcore, scenes  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C4", "C5", "tiny"])
+    ap.add_argument("--spp", type=int, default=256, help="samples per pixel per step")
+    ap.add_argument("--mode", default="path", choices=["path", "wavefront"], help="pt_render scheduling (same results)")
+    ap.add_argument("--shard", default="samples", choices=["samples", "tiles"], help="how N > 1 ranks split a frame")
+    ap.add_argument("--depth", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline-replay", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the spp sweep and the C1 entry")
+    return ap.parse_args()
 
-WORKLOADS = {
+
+def launch_ranks(n):
+    """--gpus N without a launcher: start N ranks ourselves (before any GPU call in this process)."""
+    import socket
+    import torch
+    have = torch.cuda.device_count()  # counting devices does not initialise the GPU
+    if have < n:
+        print(f"bench.py: --gpus {n} asked for, {have} GPU(s) visible", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def workloads(scenes):
     # name: (scene factory, width, height, camera origin, camera target, description)
-    "C3": (lambda: scenes.statue_scene(), 1920, 1080, scenes.CAMERA_ORIGIN, scenes.CAMERA_TARGET,
-           "C3 glass statue 871414+3 tris on diffuse floor, 1920x1080, depth 32"),
-    "C2": (lambda: scenes.glass_cube_scene(), 1920, 1080, scenes.CAMERA_ORIGIN, scenes.CAMERA_TARGET,
-           "C2 glass cube 12+3 tris on diffuse floor, 1920x1080, depth 32"),
-    "C4": (lambda: scenes.statue_scene(1042, 520, 1009, 7, scenes.GLASS_BLUE, 0.5), 3840, 2160, scenes.CAMERA_ORIGIN,
-           scenes.CAMERA_TARGET, "C4 glass statue 1087716+3 tris on semi-specular floor, 3840x2160, depth 32"),
-    "C5": (lambda: scenes.soup_scene(), 3840, 2160, scenes.CAMERA_ORIGIN, scenes.CAMERA_TARGET,
-           "C5 10M-triangle soup, 3840x2160, depth 32"),
-    "tiny": (lambda: scenes.small_mesh_scene(), 256, 144, scenes.CAMERA_ORIGIN, scenes.CAMERA_TARGET,
-             "tiny statue, 256x144 (CI)"),
-}
+    return {
+        "C3": (lambda: scenes.statue_scene(), 1920, 1080, scenes.CAMERA_ORIGIN, scenes.CAMERA_TARGET,
+               "C3 glass statue 871414+3 tris on diffuse floor, 1920x1080, depth 32"),
+        "C2": (lambda: scenes.glass_cube_scene(), 1920, 1080, scenes.CAMERA_ORIGIN, scenes.CAMERA_TARGET,
+               "C2 glass cube 12+3 tris on diffuse floor, 1920x1080, depth 32"),
+        "C4": (lambda: scenes.statue_scene(1042, 520, 1009, 7, scenes.GLASS_BLUE, 0.5), 3840, 2160, scenes.CAMERA_ORIGIN,
+               scenes.CAMERA_TARGET, "C4 glass statue 1087716+3 tris on semi-specular floor, 3840x2160, depth 32"),
+        "C5": (lambda: scenes.soup_scene(), 3840, 2160, scenes.CAMERA_ORIGIN, scenes.CAMERA_TARGET,
+               "C5 10M-triangle soup, 3840x2160, depth 32"),
+        "tiny": (lambda: scenes.small_mesh_scene(), 256, 144, scenes.CAMERA_ORIGIN, scenes.CAMERA_TARGET,
+                 "tiny statue, 256x144 (CI)"),
+    }
 
 
 def cpu_baseline(scene, sky, cam_o, cam_t, width, height, depth, seconds_hint=20.0):
@@ -77,36 +120,107 @@ def cpu_baseline(scene, sky, cam_o, cam_t, width, height, depth, seconds_hint=20
     dt = time.time() - t0
     c = o.counters()
     rays = c["rays_closest"] + c["rays_any"]
+    o.close()
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
             "mpaths_per_s": c["paths"] / dt / 1e6,
             "sample": f"{spp} spp of the {w}x{h} frame of the same scene ({c['paths']} paths, {rays} rays incl. the "
                       f"reference's shadow rays), C++ restatement of the reference (g++ -O2), static row bands, {dt:.1f} s wall"}
 
 
+def c1_entry(ptcore, scenes, sky, device):
+    """BASELINE configs[0]: the reference sphere scene, 512x512, 1 spp per frame, on the CPU threaded path
+    (oracle, static row bands, literal NEE) — and the same frames on the GPU (queued 1-spp calls)."""
+    from oracle import orc
+    threads = min(16, os.cpu_count() or 1)
+    scene = scenes.default_scene()
+    W = H = 512
+    frames = 40
+    o = orc.from_scene(scene, sky)
+    o.set_camera(scenes.SPHERE_CAMERA_ORIGIN, scenes.SPHERE_CAMERA_TARGET, W, H)
+    o.render(2, 32, seed=1, nthreads=threads, nee_mode=0)  # warm
+    o.reset_counters()
+    t0 = time.time()
+    for f in range(frames):
+        o.render(1, 32, seed=3, sample_begin=2 + f, nthreads=threads, nee_mode=0)  # one frame of main.rs:143-170
+    dt = time.time() - t0
+    c = o.counters()
+    cpu_rays = c["rays_closest"] + c["rays_any"]
+    o.close()
+    g = ptcore.PathTracer(device).set_scene(scene, sky)
+    g.set_camera(scenes.SPHERE_CAMERA_ORIGIN, scenes.SPHERE_CAMERA_TARGET, W, H)
+    for _ in range(8):
+        g.render_async(1, 32, seed=3)
+    g.wait()
+    g.reset_counters()
+    gframes = 400
+    t0 = time.perf_counter()
+    for _ in range(gframes):
+        g.render_async(1, 32, seed=3)
+    g.wait()
+    gdt = time.perf_counter() - t0
+    gc = g.counters()
+    g.close()
+    return {"C1": {"workload": "reference sphere scene (src/scene.rs:98-160), 512x512, 1 spp per frame, depth 32",
+                   "cpu": {"mrays_per_s": cpu_rays / dt / 1e6, "mpaths_per_s": c["paths"] / dt / 1e6, "fps": frames / dt, "cores": threads,
+                           "kind": "port", "frames": frames,
+                           "note": "oracle in the reference's threading mode (static row bands, shadow rays traced as the reference does)"},
+                   "gpu": {"mrays_per_s": (gc["rays_closest"] + gc["rays_any"]) / gdt / 1e6, "mpaths_per_s": gc["paths"] / gdt / 1e6,
+                           "fps": gframes / gdt, "frames": gframes, "note": "1-spp calls queued with pt_render_async, one wait at the end"}}}
+
+
+def spp_sweep(g, ptcore, W, H, depth, seed):
+    """Mrays/s against samples per call: queued calls (pt_render_async + one pt_wait) and, for 1 spp, blocking calls
+    (the reference's loop shows every frame: main.rs:143-175)."""
+    out = {}
+    for spp, calls in ((1, 64), (8, 16), (64, 4)):
+        g.reset_accum()
+        for _ in range(2):
+            g.render_async(spp, depth, seed)
+        g.wait()
+        g.reset_counters()
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            g.render_async(spp, depth, seed)
+        g.wait()
+        dt = time.perf_counter() - t0
+        c = g.counters()
+        out[f"{spp}_spp_per_call_queued"] = {"mrays_per_s": (c["rays_closest"] + c["rays_any"]) / dt / 1e6, "ms_per_call": dt * 1e3 / calls, "calls": calls}
+    g.reset_accum()
+    g.render(1, depth, seed)
+    g.reset_counters()
+    t0 = time.perf_counter()
+    for _ in range(16):
+        g.render(1, depth, seed)
+    dt = time.perf_counter() - t0
+    c = g.counters()
+    out["1_spp_per_call_blocking"] = {"mrays_per_s": (c["rays_closest"] + c["rays_any"]) / dt / 1e6, "ms_per_call": dt * 1e3 / 16, "calls": 16}
+    return out
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="C3", choices=list(WORKLOADS))
-    ap.add_argument("--spp", type=int, default=256, help="samples per pixel per step")
-    ap.add_argument("--mode", default="path", choices=["path", "wavefront"], help="pt_render scheduling (same results)")
-    ap.add_argument("--depth", type=int, default=32)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline-replay", action="store_true")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
+
+    import torch  # imported before libptcore so both share one HIP runtime
+    import torch.distributed as dist
+    from pathtracer_amd import dist as ptdist
+    from pathtracer_amd import ptcore, scenes
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = "RANK" in os.environ  # launched by torch.distributed.run (also with one rank: same code path)
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
     if use_dist:
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     device = local_rank if use_dist else 0
     torch.cuda.set_device(device)
 
-    make, W, H, cam_o, cam_t, desc = WORKLOADS[args.workload]
+    make, W, H, cam_o, cam_t, desc = workloads(scenes)[args.workload]
     scene = make()
     sky = scenes.make_sky()
     g = ptcore.PathTracer(device).set_scene(scene, sky)
@@ -114,14 +228,25 @@ def main():
     g.set_option(ptcore.OPT_RENDER_MODE, 1 if args.mode == "path" else 0)
     seed = 2026
     spp = args.spp
+    tiles = args.shard == "tiles" and world > 1
 
-    def sample_begin(step):
+    def shard_for(step):
+        if tiles:   # this rank's tiles, every sample of the step
+            return ptdist.tile_shard(rank, world, ptdist.TILE, step * spp)
         # global sample indices: step-major, then rank (weak scaling: every rank adds its own samples)
-        return (step * world + rank) * spp
+        return ptcore.Shard(ptcore.SHARD_ALL, 0, 1, 0, ptdist.sample_begin(step, rank, world, spp))
 
     def run_steps(first, count, flags):
         for s in range(first, first + count):
-            g.render(spp, args.depth, seed, ptcore.Shard(ptcore.SHARD_ALL, 0, 1, 0, sample_begin(s)), flags)
+            g.render(spp, args.depth, seed, shard_for(s), flags)
+
+    def combine():
+        if not use_dist:
+            return
+        if tiles:
+            ptdist.gather_tiles(g)
+        else:
+            ptdist.reduce_samples(g, spp_of_other_ranks=float((world - 1) * spp * args.steps))
 
     def barrier():
         torch.cuda.synchronize()
@@ -130,7 +255,7 @@ def main():
         torch.cuda.synchronize()
 
     # ---- instrumented replay of the exact timed steps (untimed): algorithmic node / primitive tests
-    bytes_total = None
+    alg = None
     if not args.no_roofline_replay:
         g.reset_counters()
         run_steps(args.warmup, args.steps, ptcore.RENDER_COUNT)
@@ -140,32 +265,31 @@ def main():
             # k_path does everything: every ray's traversal bytes plus the shading bytes of SURVEY 8d.
             # bounces (shaded hits) >= rays - paths: every ray after a path's first needs a hit before it.
             k_rays, k_nodes, k_prims = rays_replay, c["node_tests"], c["prim_tests"]
-            bounces = max(rays_replay - c["paths"], 0)
-            shade_bytes = 100 * bounces + 36 * c["paths"]
+            shade_bytes = 100 * max(rays_replay - c["paths"], 0) + 36 * c["paths"]
         else:
             # the round kernel (k_extend) alone: rays finished by the fused tail kernel are not its work
             k_rays = rays_replay - c["tail_rays"]
             k_nodes = c["node_tests"] - c["tail_node_tests"]
             k_prims = c["prim_tests"] - c["tail_prim_tests"]
             shade_bytes = 0
-        bytes_total = 32 * k_nodes + 36 * k_prims + (28 + 12) * k_rays + shade_bytes
-        nodes_per_ray = k_nodes / max(k_rays, 1)
-        prims_per_ray = k_prims / max(k_rays, 1)
-        tail_share = c["tail_rays"] / max(rays_replay, 1)
+        alg = {"bytes": 32 * k_nodes + 36 * k_prims + (28 + 12) * k_rays + shade_bytes, "rays": k_rays,
+               "node_tests_per_ray": k_nodes / max(k_rays, 1), "prim_tests_per_ray": k_prims / max(k_rays, 1),
+               "tail_share": c["tail_rays"] / max(rays_replay, 1), "tail_launches": c["tail_launches"]}
 
     # ---- warmup + timed region
     g.reset_accum()
     run_steps(0, args.warmup, 0)
     if use_dist:
         # warm the collective too (communicator channels and buffers for this message size are set up on first use)
-        dist.reduce(torch.zeros(H, W, 3, dtype=torch.float32, device=f"cuda:{device}"), dst=0, op=dist.ReduceOp.SUM)
+        if tiles:
+            ptdist.gather_tiles(g)
+        else:
+            dist.reduce(torch.zeros(H, W, 3, dtype=torch.float32, device=f"cuda:{device}"), dst=0, op=dist.ReduceOp.SUM)
     g.reset_counters()
     barrier()
     t0 = time.perf_counter()
     run_steps(args.warmup, args.steps, ptcore.RENDER_TIMED)
-    if use_dist:
-        acc = torch.as_tensor(ptcore.AccumView(g), device=f"cuda:{device}")
-        dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)  # readout: one collective per frame, not per bounce
+    combine()  # readout: one collective per frame, not per bounce
     barrier()
     dt = time.perf_counter() - t0
     c = g.counters()
@@ -181,45 +305,82 @@ def main():
     rays_all, paths_all = float(work[0].item()), float(work[1].item())
 
     if rank == 0:
+        if world == 1:
+            par = "1 GPU"
+        elif tiles:
+            par = f"tile-sharded x{world} (64x64 tiles round-robin), one gather of tile slabs at readout"
+        else:
+            par = f"sample-sharded x{world}, one reduce at readout"
         out = {
             "metric": "Mrays/sec", "value": rays_all / dt_max / 1e6, "unit": "Mrays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max * 1e3 / max(args.steps, 1),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": desc, "spp_per_step": spp, "max_depth": args.depth,
-                       "parallelism": "1 GPU" if world == 1 else f"sample-sharded x{world}, one reduce at readout",
-                       "paths_per_step_per_gpu": W * H * spp},
+            "higher_is_better": True, "scaling": "strong" if tiles else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "spp_per_step": spp, "max_depth": args.depth, "parallelism": par,
+                       "paths_per_step_per_gpu": (W * H * spp) // (world if tiles else 1)},
             "mpaths_per_s": paths_all / dt_max / 1e6,
             "rays_per_path": rays_all / max(paths_all, 1),
         }
-        k_ms = c["tail_ms"] if args.mode == "path" else c["extend_ms"]
-        if bytes_total is not None and k_ms > 0:
-            launches = max(c["tail_launches"] if args.mode == "path" else c["extend_launches"], 1)
-            achieved = bytes_total / (k_ms * 1e-3) / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
-            if os.path.exists(tpath):
-                with open(tpath) as f:
-                    tj = json.load(f)
-                key = f"{args.workload}:{args.mode}:{spp}:{args.depth}"
-                if key in tj:
-                    traffic = tj[key]["bytes_per_launch"]
-            out["roofline"] = {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "kernel": "k_path" if args.mode == "path" else "k_extend", "launches": launches,
-                "avg_launch_ms": k_ms / launches, "bytes_per_launch": bytes_total / launches,
-                "bytes_per_ray": bytes_total / max(k_rays, 1), "node_tests_per_ray": nodes_per_ray,
-                "prim_tests_per_ray": prims_per_ray, "kernel_rays": k_rays,
-                "kernel_mrays_per_s": k_rays / (k_ms * 1e-3) / 1e6,
-                "note": "HBM roof as the contract asks; the kernel's real limiters are VALU issue and memory latency "
-                        "(divergent 64-B node fetches served by L2 / Infinity Cache), see DESIGN.md and profiles/",
+        k_ms = c["tail_ms"] if args.mode == "path" else c["extend_ms"]          # time with >= 1 launch running
+        k_ms_sum = c["tail_ms_sum"] if args.mode == "path" else c["extend_ms_sum"]  # sum of launch durations
+        launches = max(c["tail_launches"] if args.mode == "path" else c["extend_launches"], 1)
+        if alg is not None and k_ms > 0:
+            kernel = "k_path" if args.mode == "path" else "k_extend"
+            alg_gbs = alg["bytes"] / (k_ms * 1e-3) / 1e9
+            roof = {
+                "kernel": kernel, "launches": launches, "avg_launch_ms": k_ms_sum / launches, "kernel_busy_ms": k_ms,
+                "kernel_rays": alg["rays"], "kernel_mrays_per_s": alg["rays"] / (k_ms * 1e-3) / 1e6,
+                "algorithmic": {"bytes_per_launch": alg["bytes"] / launches, "bytes_per_ray": alg["bytes"] / max(alg["rays"], 1),
+                                "node_tests_per_ray": alg["node_tests_per_ray"], "prim_tests_per_ray": alg["prim_tests_per_ray"],
+                                "gb_per_s": alg_gbs, "over_hbm_peak": alg_gbs / HBM_PEAK_GBS,
+                                "note": "SURVEY 8(d) bytes the algorithm asks for; served mostly by L1 / L2 / Infinity Cache, so this is not an HBM fraction"},
             }
+            pmc = cal = None
+            if os.path.exists(PMC_FILE):
+                with open(PMC_FILE) as f:
+                    table = json.load(f)
+                pmc, cal = table.get(f"{args.workload}:{args.mode}:{spp}:{args.depth}"), table.get("_calibration")
+            ms_per_launch = k_ms / launches
+            if pmc and world == 1:
+                hbm_gbs = pmc["hbm_bytes_per_launch"] / (ms_per_launch * 1e-3) / 1e9
+                valu_gwips = pmc["valu_wave_insts_per_launch"] / (ms_per_launch * 1e-3) / 1e9
+                hbm_frac, valu_frac = hbm_gbs / HBM_PEAK_GBS, valu_gwips / VALU_PEAK_GWIPS
+                roof["hbm"] = {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac,
+                               "fetch_bytes_per_launch": pmc["fetch_bytes_per_launch"], "write_bytes_per_launch": pmc["write_bytes_per_launch"],
+                               "note": pmc.get("hbm_note", "")}
+                roof["valu"] = {"achieved": valu_gwips, "peak": VALU_PEAK_GWIPS, "unit": "G wave-inst/s", "frac": valu_frac,
+                                "lane_util": pmc["lane_util"], "lane_frac": valu_frac * pmc["lane_util"],
+                                "valu_wave_insts_per_ray": pmc["valu_wave_insts_per_launch"] * launches / max(alg["rays"], 1),
+                                "note": "wave64 VALU instructions issued / (1024 SIMDs x 2.4 GHz / 4 cycles); lane_util = active lanes per instruction / 64; "
+                                        "lane_frac = fraction of the lane-issue peak doing work"}
+                if cal:
+                    req = pmc["ea_read_requests_per_launch"] / (ms_per_launch * 1e-3) / 1e9
+                    peak_ic = cal["fabric_gather_peak_g_requests_per_s_infinity_cache"]
+                    roof["fabric_gather"] = {"achieved": req, "peak": peak_ic, "unit": "G 64-B read requests/s", "frac": req / peak_ic,
+                                             "peak_hbm_resident": cal["fabric_gather_peak_g_requests_per_s_hbm"], "l2_hit_rate": pmc["l2_hit_rate"],
+                                             "note": "L2-miss read requests (TCC_EA0_RDREQ) per second against the rate a pure random 64-B-record gather reaches on "
+                                                     "this GPU (tools/calib.hip, profiles/r2_calib.json: table resident in the Infinity Cache / in HBM only). "
+                                                     "A MEASURED peak, not a spec figure, so it is reported beside the headline, not as it"}
+                roof["traffic"] = pmc["hbm_bytes_per_launch"]
+                roof["pmc_source"] = pmc.get("source", "profiles/r2_pmc.json")
+                top = "valu" if valu_frac >= hbm_frac else "hbm"
+                roof.update({"bound": top, "achieved": roof[top]["achieved"], "peak": roof[top]["peak"], "unit": roof[top]["unit"],
+                             "frac": roof[top]["frac"]})
+            else:
+                roof.update({"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                             "note": "no PMC passes committed for this configuration (profiles/r2_pmc.json): only the algorithmic figure is live"})
+            out["roofline"] = roof
             if args.mode != "path":
-                out["tail"] = {"share_of_rays": tail_share, "launches": c["tail_launches"], "ms_total": c["tail_ms"]}
+                out["tail"] = {"share_of_rays": alg["tail_share"], "launches": c["tail_launches"], "ms_busy": c["tail_ms"]}
+        if world == 1 and not args.no_extras:
+            out["spp_sweep"] = spp_sweep(g, ptcore, W, H, args.depth, seed)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, sky, cam_o, cam_t, W, H, args.depth)
+            if not args.no_extras:
+                out["cpu_configs"] = c1_entry(ptcore, scenes, sky, device)
         print(json.dumps(out), flush=True)
     g.close()
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 

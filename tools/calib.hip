@@ -1,0 +1,121 @@
+// calib.hip — micro-kernels that calibrate the two roofs bench.py prices k_path against (gfx950):
+//   stream    wide coalesced 16-B-per-lane read of a buffer          -> what FETCH_SIZE reports per streamed byte
+//   gather64  one random 64-B record (4 x 16 B) per lane, every record of the table read exactly once,
+//             the access shape of k_path's node fetch           -> what FETCH_SIZE reports per gathered byte, and the
+//             rate at which HBM / Infinity Cache serve such gathers (the roof of the C5 soup)
+//   valu      independent fp32 adds / multiplies, 6 waves per SIMD   -> VALU wave-instruction issue peak
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o tools/calib tools/calib.hip
+// Run:   tools/calib <stream|gather64|valu> [MiB] [reps] [noflush]   (one JSON line per repetition; also under rocprofv3 --pmc FETCH_SIZE)
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#define CK(x)                                                                              \
+    do {                                                                                   \
+        hipError_t e_ = (x);                                                               \
+        if (e_ != hipSuccess) {                                                            \
+            std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));                   \
+            return 1;                                                                      \
+        }                                                                                  \
+    } while (0)
+
+__global__ __launch_bounds__(256) void k_stream(const float4* __restrict__ src, size_t n, float* __restrict__ out) {
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = src[i];
+        acc += v.x + v.y + v.z + v.w;
+    }
+    if (acc == 123.456f) out[0] = acc;  // never true: keeps the loads
+}
+
+// record index of lane i: an odd multiplier modulo a power of two is a permutation, so every record is read once
+__global__ __launch_bounds__(64) void k_gather64(const float4* __restrict__ table, uint32_t n_records_log2, uint32_t per_lane, float* __restrict__ out) {
+    const uint32_t mask = (1u << n_records_log2) - 1u;
+    const uint32_t lanes = gridDim.x * blockDim.x;
+    const uint32_t me = blockIdx.x * blockDim.x + threadIdx.x;
+    float acc = 0.f;
+    for (uint32_t k = 0; k < per_lane; ++k) {
+        const uint32_t i = (k * lanes + me);
+        const uint32_t rec = (i * 2654435761u + 12345u) & mask;
+        const float4* p = table + (size_t)rec * 4;
+        const float4 a = p[0], b = p[1], c = p[2], d = p[3];
+        acc += a.x + b.y + c.z + d.w;
+    }
+    if (acc == 123.456f) out[0] = acc;
+}
+
+__global__ __launch_bounds__(64) void k_valu(uint32_t iters, float seed, float* __restrict__ out) {
+    float a0 = seed + threadIdx.x, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+    for (uint32_t i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {  // 16 x 8 = 128 independent VALU instructions per iteration
+            a0 = a0 * 1.0000001f; a1 = a1 + 0.5f; a2 = a2 * 0.9999999f; a3 = a3 + 0.25f;
+            a4 = a4 * 1.0000002f; a5 = a5 + 0.125f; a6 = a6 * 0.9999998f; a7 = a7 + 0.0625f;
+        }
+    }
+    const float s = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+    if (s == 123.456f) out[0] = s;
+}
+
+int main(int argc, char** argv) {
+    const char* what = argc > 1 ? argv[1] : "stream";
+    const size_t mib = argc > 2 ? (size_t)std::atoll(argv[2]) : 4096;
+    const int reps = argc > 3 ? std::atoi(argv[3]) : 3;
+    const bool noflush = argc > 4 && !std::strcmp(argv[4], "noflush");  // keep the table in L2 / Infinity Cache between repetitions
+    CK(hipSetDevice(0));
+    float* out = nullptr;
+    CK(hipMalloc(&out, 256));
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    if (!std::strcmp(what, "valu")) {
+        const uint32_t iters = 20000, grid = 256 * 24;
+        for (int r = 0; r < reps; ++r) {
+            CK(hipEventRecord(a, 0));
+            hipLaunchKernelGGL(k_valu, dim3(grid), dim3(64), 0, 0, iters, 1.0f, out);
+            CK(hipEventRecord(b, 0));
+            CK(hipEventSynchronize(b));
+            float ms = 0;
+            CK(hipEventElapsedTime(&ms, a, b));
+            const double insts = (double)grid * iters * 128;
+            std::printf("{\"kernel\": \"valu\", \"waves\": %u, \"wave_insts\": %.0f, \"ms\": %.3f, \"g_wave_insts_per_s\": %.1f}\n", grid, insts, ms,
+                        insts / (ms * 1e-3) / 1e9);
+        }
+        return 0;
+    }
+    size_t bytes = mib << 20;
+    uint32_t log2rec = 0;
+    while (((size_t)64 << (log2rec + 1)) <= bytes) ++log2rec;
+    if (!std::strcmp(what, "gather64")) bytes = (size_t)64 << log2rec;  // power-of-two record count
+    float4* buf = nullptr;
+    CK(hipMalloc(&buf, bytes));
+    CK(hipMemset(buf, 0, bytes));
+    // a second buffer written between repetitions pushes the table out of L2 / Infinity Cache
+    float4* flush = nullptr;
+    const size_t flush_bytes = (size_t)1 << 30;
+    CK(hipMalloc(&flush, flush_bytes));
+    for (int r = 0; r < reps; ++r) {
+        if (!noflush) CK(hipMemset(flush, r, flush_bytes));
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(a, 0));
+        if (!std::strcmp(what, "stream")) {
+            hipLaunchKernelGGL(k_stream, dim3(256 * 8), dim3(256), 0, 0, buf, bytes / 16, out);
+        } else {
+            const uint32_t n_rec = 1u << log2rec, lanes = 256 * 24 * 64;
+            const uint32_t per_lane = n_rec / lanes;  // table sizes here are multiples of 24 MiB x 2^k only approximately: the rest is not read
+            hipLaunchKernelGGL(k_gather64, dim3(256 * 24), dim3(64), 0, 0, buf, log2rec, per_lane, out);
+            bytes = (size_t)per_lane * lanes * 64;
+        }
+        CK(hipEventRecord(b, 0));
+        CK(hipEventSynchronize(b));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, a, b));
+        std::printf("{\"kernel\": \"%s\", \"table_mib\": %zu, \"bytes_read\": %zu, \"ms\": %.3f, \"gb_per_s\": %.1f}\n", what, mib, bytes, ms,
+                    bytes / (ms * 1e-3) / 1e9);
+    }
+    return 0;
+}

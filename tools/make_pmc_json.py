@@ -1,0 +1,98 @@
+"""Collects the round-2 evidence under gpurun_out/r2/ into profiles/ (tracked):
+  profiles/r2_<tag>_{bench.json,kernel_stats.csv,pmc_k_path.json}   per profiled workload (tools/profile_r2.sh)
+  profiles/r2_calib.json                                           calibration of FETCH_SIZE and of the VALU issue peak (tools/calib_r2.sh)
+  profiles/r2_pmc.json                                             what bench.py reads: per-launch counters of k_path keyed workload:mode:spp:depth
+usage: python3 tools/make_pmc_json.py tag=WORKLOAD:SPP ..."""
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "r2")
+DST = os.path.join(ROOT, "profiles")
+
+
+def calib():
+    c = os.path.join(SRC, "calib")
+    if not os.path.isdir(c):
+        return None
+
+    def lines(name):
+        return [json.loads(ln) for ln in open(os.path.join(c, name)) if ln.startswith("{")]
+
+    def pmc(name):
+        return list(json.load(open(os.path.join(c, name))).values())
+
+    stream, g_hbm, g_mall, valu = lines("stream.txt"), lines("gather_hbm.txt"), lines("gather_mall.txt"), lines("valu.txt")
+    p_stream, p_hbm, p_mall, p_req = pmc("p_stream.json")[0], pmc("p_gather_hbm.json")[0], pmc("p_gather_mall.json")[0], pmc("p_gather_req.json")[0]
+    p_valu, p_clk = pmc("p_valu.json")
+    best = lambda rows, k: max(r[k] for r in rows)
+    out = {
+        "how": "tools/calib.hip through tools/calib_r2.sh on one MI355X; FETCH_SIZE is reported in KiB",
+        "stream_16B_per_lane": {"bytes_read": stream[0]["bytes_read"], "best_gb_per_s": best(stream, "gb_per_s"),
+                                "FETCH_SIZE_bytes": p_stream["FETCH_SIZE"] * 1024, "fetch_size_over_bytes": p_stream["FETCH_SIZE"] * 1024 / stream[0]["bytes_read"]},
+        "gather_64B_records_hbm_4GiB": {"bytes_read": g_hbm[0]["bytes_read"], "best_gb_per_s": best(g_hbm, "gb_per_s"),
+                                        "FETCH_SIZE_bytes": p_hbm["FETCH_SIZE"] * 1024, "fetch_size_over_bytes": p_hbm["FETCH_SIZE"] * 1024 / g_hbm[0]["bytes_read"],
+                                        "TCC_EA0_RDREQ": p_req["TCC_EA0_RDREQ_sum"], "records": g_hbm[0]["bytes_read"] // 64,
+                                        "g_requests_per_s": best(g_hbm, "gb_per_s") / 64},
+        "gather_64B_records_infinity_cache_128MiB": {"bytes_read": g_mall[0]["bytes_read"], "best_gb_per_s": best(g_mall[1:], "gb_per_s"),
+                                                     "FETCH_SIZE_bytes": p_mall["FETCH_SIZE"] * 1024,
+                                                     "fetch_size_over_bytes": p_mall["FETCH_SIZE"] * 1024 / g_mall[0]["bytes_read"],
+                                                     "g_requests_per_s": best(g_mall[1:], "gb_per_s") / 64},
+        "valu_issue": {"waves": valu[0]["waves"], "source_ops": valu[0]["wave_insts"], "best_ms": min(r["ms"] for r in valu),
+                       "SQ_INSTS_VALU": p_valu["SQ_INSTS_VALU"], "SQ_ACTIVE_INST_VALU": p_valu["SQ_ACTIVE_INST_VALU"],
+                       "note": "the compiler packs the 8 independent chains pairwise (v_pk_mul_f32 / v_pk_add_f32), so the launch issues half as many "
+                               "wave instructions as the source has operations; rates below use the counted instructions",
+                       "ms_under_pmc": p_valu["dur_ms"], "clock_ghz_under_pmc": p_clk["GRBM_GUI_ACTIVE"] / 8 / (p_clk["dur_ms"] * 1e6),
+                       "g_wave_insts_per_s_under_pmc": p_valu["SQ_INSTS_VALU"] / (p_valu["dur_ms"] * 1e6),
+                       "g_wave_insts_per_s_best": p_valu["SQ_INSTS_VALU"] / (min(r["ms"] for r in valu) * 1e6),
+                       "simd_cycles_per_wave_inst": 1024 * p_clk["GRBM_GUI_ACTIVE"] / 8 / (p_clk["dur_ms"] * 1e6) / (p_valu["SQ_INSTS_VALU"] / (p_valu["dur_ms"] * 1e6))},
+    }
+    json.dump(out, open(os.path.join(DST, "r2_calib.json"), "w"), indent=1)
+    return out
+
+
+def main():
+    cal = calib()
+    path = os.path.join(DST, "r2_pmc.json")
+    table = json.load(open(path)) if os.path.exists(path) else {}
+    for arg in sys.argv[1:]:
+        tag, rest = arg.split("=")
+        wl, spp = rest.split(":")
+        d = os.path.join(SRC, tag)
+        p = json.load(open(os.path.join(d, "pmc.json")))
+        shutil.copy(os.path.join(d, "pmc.json"), os.path.join(DST, f"r2_{tag}_pmc_k_path.json"))
+        shutil.copy(os.path.join(d, "bench.json"), os.path.join(DST, f"r2_{tag}_bench.json"))
+        if os.path.exists(os.path.join(d, "kernel_stats.csv")):
+            shutil.copy(os.path.join(d, "kernel_stats.csv"), os.path.join(DST, f"r2_{tag}_kernel_stats.csv"))
+        fetch, write = p["fetch"]["FETCH_SIZE"] * 1024, p["write"]["WRITE_SIZE"] * 1024
+        sq1, sq2, tcc, grbm = p["sq1"], p["sq2"], p["tcc"], p["grbm"]
+        table[f"{wl}:path:{spp}:32"] = {
+            "source": f"profiles/r2_{tag}_pmc_k_path.json (tools/profile_r2.sh {tag} {wl} {spp}: one rocprofv3 --pmc pass per counter group over `bench.py --steps 1 --warmup 1`)",
+            "kernel_ms_under_pmc": sq1["dur_ms"],
+            "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write,
+            "hbm_note": "FETCH_SIZE + WRITE_SIZE (KiB x 1024) per k_path launch.  FETCH_SIZE = TCC_EA0_RDREQ x 64 B; for this kernel's read shape (one 64-B-aligned "
+                        "record per lane) profiles/r2_calib.json shows it reads the bytes exactly (ratio 1.00; the x2 of MI355X_MICROARCH.md applies to wide "
+                        "streaming reads, ratio 0.50 there), so no correction is applied.  These are L2-miss requests to the fabric: Infinity-Cache hits are "
+                        "included, HBM itself carries at most this.",
+            "ea_read_requests_per_launch": tcc["TCC_EA0_RDREQ_sum"],
+            "l2_hit_rate": tcc["TCC_HIT_sum"] / (tcc["TCC_HIT_sum"] + tcc["TCC_MISS_sum"]),
+            "valu_wave_insts_per_launch": sq1["SQ_INSTS_VALU"],
+            "lane_util": sq2["SQ_THREAD_CYCLES_VALU"] / (64.0 * sq1["SQ_ACTIVE_INST_VALU"]),
+            "salu_insts_per_launch": sq2["SQ_INSTS_SALU"], "vmem_rd_insts_per_launch": sq2["SQ_INSTS_VMEM_RD"],
+            "wave_wait_any_frac": sq1["SQ_WAIT_ANY"] / sq1["SQ_WAVE_CYCLES"],
+            "clock_ghz_under_pmc": grbm["GRBM_GUI_ACTIVE"] / 8 / (grbm["dur_ms"] * 1e6),
+        }
+    if cal:
+        table["_calibration"] = {"fabric_gather_peak_g_requests_per_s_infinity_cache": cal["gather_64B_records_infinity_cache_128MiB"]["g_requests_per_s"],
+                                 "fabric_gather_peak_g_requests_per_s_hbm": cal["gather_64B_records_hbm_4GiB"]["g_requests_per_s"],
+                                 "valu_measured_g_wave_insts_per_s": cal["valu_issue"]["g_wave_insts_per_s_best"],
+                                 "valu_simd_cycles_per_wave_inst": cal["valu_issue"]["simd_cycles_per_wave_inst"],
+                                 "source": "profiles/r2_calib.json"}
+    json.dump(table, open(path, "w"), indent=1, sort_keys=True)
+    print(json.dumps(table, indent=1)[:3000])
+
+
+if __name__ == "__main__":
+    main()
