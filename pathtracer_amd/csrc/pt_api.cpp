@@ -446,7 +446,9 @@ static int finalize_scene(pt_ctx* c) {
     c->nee = neg_nee && !c->bvh.lights.empty();
 
     FlatBVH flat;
-    int rc = flatten_bvh(c->bvh, flat);
+    // triangle leaves of kCoopLeafFrom primitives or more are marked for wave-cooperative testing (step_prim_wave);
+    // sphere leaves stay sequential (Sphere::intersect compares with ray.distance), so only the > 31 escape applies
+    int rc = flatten_bvh(c->bvh, flat, (c->prim_kind == PRIM_TRIANGLE && kCoopLeafFrom != 0) ? kCoopLeafFrom : 32u);
     if (rc) return c->fail(rc, "pt_build: flatten failed");
 
     // primitives in leaf order

@@ -299,7 +299,7 @@ void build_bvh(const std::vector<PrimInfo>& prims, HostBVH& out, int threads) {
     out.hazard = b.hazard;
 }
 
-int flatten_bvh(const HostBVH& bvh, FlatBVH& out) {
+int flatten_bvh(const HostBVH& bvh, FlatBVH& out, uint32_t big_from) {
     const size_t nn = bvh.nodes.size();
     if (bvh.indices.size() > kMaxPrims) return PT_ERR_LIMIT;
     // number the internal nodes in reference order
@@ -312,7 +312,7 @@ int flatten_bvh(const HostBVH& bvh, FlatBVH& out) {
     auto make_ref = [&](uint32_t node) -> uint32_t {
         const pt_bvh_node& n = bvh.nodes[node];
         if (n.count == 0) return pair_of[node];
-        if (n.count <= 31) return kLeafBit | (n.count << kLeafCountShift) | n.left_first;
+        if (n.count < big_from && n.count <= 31) return kLeafBit | (n.count << kLeafCountShift) | n.left_first;
         uint32_t slot = (uint32_t)(out.big_leaf.size() / 2);
         out.big_leaf.push_back(n.left_first);
         out.big_leaf.push_back(n.count);

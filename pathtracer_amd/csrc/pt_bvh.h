@@ -59,11 +59,13 @@ static_assert(sizeof(PairRecord) == 64, "pair record must be 64 bytes");
 
 struct FlatBVH {
     std::vector<PairRecord> pairs;
-    std::vector<uint32_t> big_leaf;  // (first, count) pairs for leaves with more than 31 primitives
+    std::vector<uint32_t> big_leaf;  // (first, count) pairs of the leaves referenced through the escape encoding (count field 0)
     float root_min[3], root_max[3];
     uint32_t root_ref = 0;
 };
 
-int flatten_bvh(const HostBVH& bvh, FlatBVH& out);
+// Leaves of `big_from` primitives or more (and always those above 31, which the 5-bit count field cannot hold) are
+// referenced through the escape encoding: the persistent kernels test such a leaf with the whole wave at once.
+int flatten_bvh(const HostBVH& bvh, FlatBVH& out, uint32_t big_from = 32);
 
 }  // namespace pt

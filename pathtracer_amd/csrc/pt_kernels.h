@@ -68,6 +68,10 @@ struct LaunchCfg {
 #ifndef PT_WAVES_PER_CU
 #define PT_WAVES_PER_CU 24
 #endif
+#ifndef PT_COOP_LEAF_FROM
+#define PT_COOP_LEAF_FROM 16
+#endif
+constexpr uint32_t kCoopLeafFrom = PT_COOP_LEAF_FROM;  // triangle leaves of at least this many primitives are tested by the whole wave (0 = never)
 constexpr int kTraceBlock = PT_TRACE_BLOCK;  // threads per traversal workgroup
 constexpr int kLdsStack = PT_LDS_STACK;      // stack entries per lane kept in LDS
 constexpr int kWavesPerCU = PT_WAVES_PER_CU; // persistent grid: waves launched per CU (what fits is decided by LDS and VGPRs)

@@ -596,12 +596,12 @@ __device__ __forceinline__ void test_prim(const DevScene& S, LaneTrav& T, uint32
 // One primitive step of a lane that stands at a leaf: test the leaf's next (up to two) primitives; the leaf
 // reference itself is the cursor (first += 2, count -= 2), the lane pops after the last one.
 // Leaves of more than 31 primitives (count field 0) are rare and done in one go.
-template <int PRIM, bool COUNT>
+template <int PRIM, bool COUNT, bool ESCAPE = true>
 __device__ __forceinline__ void step_prim(const DevScene& S, LaneTrav& T, bool& active, const LaneStack& stk, uint32_t& np) {
     const uint32_t first = T.cur & kLeafFirstMask;
     const uint32_t count = (T.cur >> kLeafCountShift) & 31u;
     bool done;
-    if (count == 0) {
+    if (ESCAPE && count == 0) {  // ESCAPE = false: the caller takes the escape-encoded leaves itself (step_prim_wave)
         const uint32_t bf = S.big_leaf[2 * first], bc = S.big_leaf[2 * first + 1];
         if (COUNT) np += bc;
         for (uint32_t k = 0; k < bc; ++k) test_prim<PRIM>(S, T, bf + k);
@@ -616,6 +616,76 @@ __device__ __forceinline__ void step_prim(const DevScene& S, LaneTrav& T, bool& 
         T.cur = T.cur + 2u - (2u << kLeafCountShift);
     }
     if (done && !lane_pop(T, stk)) active = false;
+}
+
+__device__ __forceinline__ float lane_bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+__device__ __forceinline__ uint32_t lane_bcast(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
+
+// The primitive step of a whole wave (every lane of the wave must call it; at_leaf says which lanes stand at a leaf).
+// Lanes at small leaves take the ordinary step above.  A lane at a LARGE leaf — the builder does not split
+// primitives whose centres coincide (bvh.rs:56,158-162: fans around one vertex, stacked copies), so leaves
+// can hold dozens — would keep the other 63 lanes waiting for dozens of sequential tests.  Triangle::intersect
+// does not look at ray.distance (triangle.rs:41-72), so which primitive of a leaf wins does not depend on the order
+// of evaluation: it is the LAST one in leaf order that accepts the ray, with that primitive's t.  The wave
+// therefore takes the large leaves one at a time: the owner's ray is broadcast, lane k tests primitive k, and the
+// highest accepting lane is the winner — the same hit, t, u, v and inside flag as the sequential loop, in one
+// test's time.  (Spheres do compare with ray.distance, sphere.rs:54,66: they stay sequential.)
+template <int PRIM, bool COUNT>
+__device__ __forceinline__ void step_prim_wave(const DevScene& S, LaneTrav& T, bool& active, bool at_leaf, const LaneStack& stk, uint32_t& np) {
+    if (PRIM != PRIM_TRIANGLE || kCoopLeafFrom == 0) {  // PT_COOP_LEAF_FROM=0: A/B builds without the cooperative path
+        if (at_leaf) step_prim<PRIM, COUNT>(S, T, active, stk, np);
+        return;
+    }
+    // large leaves carry the escape encoding (count field 0; the host marks them when it flattens the tree)
+    const bool coop = at_leaf && ((T.cur >> kLeafCountShift) & 31u) == 0u;
+    if (at_leaf && !coop) step_prim<PRIM, COUNT, false>(S, T, active, stk, np);
+    uint32_t first = 0, count = 0;
+    if (coop) {
+        const uint32_t e = T.cur & kLeafFirstMask;
+        first = S.big_leaf[2 * e];
+        count = S.big_leaf[2 * e + 1];
+    }
+    unsigned long long todo = __ballot(coop);
+    const uint32_t lane = threadIdx.x & 63u;
+    while (todo) {
+        const int src = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)todo) - 1);
+        todo &= todo - 1ull;
+        const uint32_t f = lane_bcast(first, src), n = lane_bcast(count, src);
+        const V3 o = V3{lane_bcast(T.o.x, src), lane_bcast(T.o.y, src), lane_bcast(T.o.z, src)};
+        const V3 d = V3{lane_bcast(T.d.x, src), lane_bcast(T.d.y, src), lane_bcast(T.d.z, src)};
+        uint32_t win = PT_MISS;  // wave-uniform: the last accepting primitive so far, with its hit values
+        float wt = 0.f, wu = 0.f, wv = 0.f, wdet = 0.f;
+        for (uint32_t base = 0; base < n; base += 64u) {
+            const uint32_t k = base + lane;
+            float t = 0.f, u = 0.f, v = 0.f, det = 0.f;
+            bool hit = false;
+            if (k < n) {
+                const float4* tp = S.prim + (size_t)(f + k) * 3;
+                const float4 a = tp[0], b = tp[1], c = tp[2];
+                hit = tri_hit(V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, V3{b.z, b.w, c.x}, o, d, &t, &u, &v, &det);
+            }
+            const unsigned long long m = __ballot(hit);
+            if (m) {
+                const int w = __builtin_amdgcn_readfirstlane(63 - (int)__clzll((long long)m));
+                win = f + base + (uint32_t)w;
+                wt = lane_bcast(t, w);
+                wu = lane_bcast(u, w);
+                wv = lane_bcast(v, w);
+                wdet = lane_bcast(det, w);
+            }
+        }
+        if ((int)lane == src) {
+            if (COUNT) np += n;
+            if (win != PT_MISS) {
+                T.dist = wt;  // unconditionally, triangle.rs:72
+                T.hslot = win;
+                T.hu = wu;
+                T.hv = wv;
+                T.hinside = wdet < 0.0f ? 1u : 0u;
+            }
+            if (!lane_pop(T, stk)) active = false;
+        }
+    }
 }
 
 // One traversal step of a wave in the persistent kernels: the wave does whichever kind of step
@@ -634,7 +704,7 @@ __device__ __forceinline__ void wave_step(const DevScene& S, LaneTrav& T, bool& 
                 if (active && !(T.cur & kLeafBit)) step_internal<COUNT>(S, T, active, stk, nn, mine);
         }
     } else {
-        if (at_leaf) step_prim<PRIM, COUNT>(S, T, active, stk, np);
+        step_prim_wave<PRIM, COUNT>(S, T, active, at_leaf, stk, np);
     }
 }
 
@@ -1345,7 +1415,7 @@ __global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, c
             }
             if (!internal_turn || drained) {
                 const unsigned long long t0 = st.now();
-                if (at_leaf) step_prim<PRIM, COUNT>(S, T, active, stk, np);
+                step_prim_wave<PRIM, COUNT>(S, T, active, at_leaf, stk, np);
                 st.add(3, actv & ~mi, t0);
             }
             if (!active && ((actv >> lane) & 1ull)) {
