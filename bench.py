@@ -26,7 +26,7 @@ Extra objects on the JSON line:
                bind: `hbm` = fabric traffic per launch from rocprofv3 FETCH_SIZE / WRITE_SIZE passes
                (profiles/r2_pmc.json, corrected as profiles/README.md states) / live kernel time / 8 TB/s, or
                `valu` = VALU wave-instructions per launch (SQ_INSTS_VALU pass) / live kernel time / the issue
-               peak (1024 SIMDs x 2.4 GHz / 4 cycles); `lane_util` says how full those instructions were.
+               peak (1024 SIMDs x 2.4 GHz / 2 cycles); `lane_util` says how full those instructions were.
                Kernel time is measured live with HIP events on the launching stream.
   cpu_baseline the CPU oracle (a C++ restatement of the reference, kind "port") in the reference's
                threading mode on this box's host cores, on a bounded sample of the same workload.
@@ -45,7 +45,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
-VALU_PEAK_GWIPS = 1024 * 2.4 / 4  # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz = 614.4 G wave-inst/s
+VALU_PEAK_GWIPS = 1024 * 2.4 / 2  # 256 CUs x 4 SIMDs, one plain wave64 VALU instruction per 2 cycles at 2.4 GHz (MI355X_MICROARCH.md: v_fma_f32 wave64
+                                 # 2 cyc; tools/calib.hip measures 1051 G/s at the clock the chip holds) = 1228.8 G wave-inst/s
 PMC_FILE = os.path.join(ROOT, "profiles", "r2_pmc.json")
 
 
@@ -172,9 +173,9 @@ def spp_sweep(g, ptcore, W, H, depth, seed):
     """Mrays/s against samples per call: queued calls (pt_render_async + one pt_wait) and, for 1 spp, blocking calls
     (the reference's loop shows every frame: main.rs:143-175)."""
     out = {}
-    for spp, calls in ((1, 64), (8, 16), (64, 4)):
+    for spp, calls in ((1, 64), (8, 16), (64, 8)):
         g.reset_accum()
-        for _ in range(2):
+        for _ in range(calls):   # untimed pass of the same shape: every lane's buffers exist before the timed one
             g.render_async(spp, depth, seed)
         g.wait()
         g.reset_counters()
@@ -199,6 +200,11 @@ def spp_sweep(g, ptcore, W, H, depth, seed):
 
 def main():
     args = parse_args()
+    # Hardware queues of this process (read by the HIP runtime when it starts; its default is 4).  Queued render calls
+    # run on up to eight streams, and streams that share a hardware queue run their kernels one after the other: with 8
+    # queues the 1-spp-per-call rate of the spp sweep rises by 30 % (1.25 -> 1.6 Grays/s); the headline (one launch of
+    # 256 spp per step) does not depend on it.  An existing setting in the environment wins.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(args.gpus))
 
@@ -319,6 +325,7 @@ def main():
                        "paths_per_step_per_gpu": (W * H * spp) // (world if tiles else 1)},
             "mpaths_per_s": paths_all / dt_max / 1e6,
             "rays_per_path": rays_all / max(paths_all, 1),
+            "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
         }
         k_ms = c["tail_ms"] if args.mode == "path" else c["extend_ms"]          # time with >= 1 launch running
         k_ms_sum = c["tail_ms_sum"] if args.mode == "path" else c["extend_ms_sum"]  # sum of launch durations
@@ -350,7 +357,7 @@ def main():
                 roof["valu"] = {"achieved": valu_gwips, "peak": VALU_PEAK_GWIPS, "unit": "G wave-inst/s", "frac": valu_frac,
                                 "lane_util": pmc["lane_util"], "lane_frac": valu_frac * pmc["lane_util"],
                                 "valu_wave_insts_per_ray": pmc["valu_wave_insts_per_launch"] * launches / max(alg["rays"], 1),
-                                "note": "wave64 VALU instructions issued / (1024 SIMDs x 2.4 GHz / 4 cycles); lane_util = active lanes per instruction / 64; "
+                                "note": "wave64 VALU instructions issued / (1024 SIMDs x 2.4 GHz / 2 cycles: the rate of plain fp32 instructions; divides, v_mul_hi and packed ops issue slower, so the pipe is busier than this says); lane_util = active lanes per instruction / 64; "
                                         "lane_frac = fraction of the lane-issue peak doing work"}
                 if cal:
                     req = pmc["ea_read_requests_per_launch"] / (ms_per_launch * 1e-3) / 1e9

@@ -1076,11 +1076,13 @@ int pt_render_async(pt_ctx* c, uint32_t spp, uint32_t max_depth, uint64_t seed, 
     J.per_batch = per_batch;
     J.batch_slots = per_batch * M.npix_pad;
     J.n_batches = (uint32_t)((spp + per_batch - 1) / per_batch);
-    // path-kernel mode: two launches in flight cover each other's ends when the batches are large (more measured
-    // no faster, and the radiance slabs stay within 2 x 8 GB); small batches (few samples per call) are mostly
-    // end, so up to eight of them overlap.  The wavefront rounds need all eight.
+    // path-kernel mode: launches in flight cover each other's ends (a launch ends with a few long paths in nearly empty
+    // waves).  Small batches (few samples per call) are mostly end, so up to eight of them overlap (C3: 1 spp per call
+    // 0.76 -> 1.25 Grays/s, 8 spp 4.2 -> 6.6, 64 spp 10.3 -> 10.8 with 2 -> 8 in flight); every launch in flight holds a
+    // radiance slab of 16 B per path, so large batches stay at two (more measured no faster there): the slabs of all
+    // lanes together are kept under 24 GiB.  The wavefront rounds need all eight.
     uint64_t want_lanes = c->opt_lanes;
-    if (!want_lanes) want_lanes = c->opt_render_mode == 1 ? std::min<uint64_t>(kMaxLanes, std::max<uint64_t>(2, kPathBatchSlots / 4 / J.batch_slots)) : kMaxLanes;
+    if (!want_lanes) want_lanes = c->opt_render_mode == 1 ? std::min<uint64_t>(kMaxLanes, std::max<uint64_t>(2, (24ull << 30) / (J.batch_slots * 16))) : kMaxLanes;
     J.max_lanes = (uint32_t)want_lanes;
     J.spp = spp;
     J.sample_begin = sample_begin;

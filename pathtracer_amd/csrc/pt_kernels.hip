@@ -618,6 +618,11 @@ __device__ __forceinline__ void step_prim(const DevScene& S, LaneTrav& T, bool& 
     if (done && !lane_pop(T, stk)) active = false;
 }
 
+#ifndef PT_COOP_LANES_PER_PRIM
+#define PT_COOP_LANES_PER_PRIM 2
+#endif
+constexpr int kCoopLanesPerPrim = PT_COOP_LANES_PER_PRIM;  // a large leaf is taken cooperatively when lanes-at-large-leaves * this <= its primitives
+
 __device__ __forceinline__ float lane_bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
 __device__ __forceinline__ uint32_t lane_bcast(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
 
@@ -637,14 +642,23 @@ __device__ __forceinline__ void step_prim_wave(const DevScene& S, LaneTrav& T, b
         return;
     }
     // large leaves carry the escape encoding (count field 0; the host marks them when it flattens the tree)
-    const bool coop = at_leaf && ((T.cur >> kLeafCountShift) & 31u) == 0u;
-    if (at_leaf && !coop) step_prim<PRIM, COUNT, false>(S, T, active, stk, np);
+    const bool esc = at_leaf && ((T.cur >> kLeafCountShift) & 31u) == 0u;
+    if (at_leaf && !esc) step_prim<PRIM, COUNT, false>(S, T, active, stk, np);
+    const unsigned long long escm = __ballot(esc);
+    if (escm == 0) return;
     uint32_t first = 0, count = 0;
-    if (coop) {
+    if (esc) {
         const uint32_t e = T.cur & kLeafFirstMask;
         first = S.big_leaf[2 * e];
         count = S.big_leaf[2 * e + 1];
     }
+    // One cooperative pass per lane costs about two ordinary steps.  When many lanes of the wave stand at large
+    // leaves at once (coherent rays reach the same fan together), the ordinary lock-step steps of two primitives are
+    // cheaper for the medium-sized ones: such a lane gets its leaf back as an ordinary reference and takes part in the
+    // next leaf turns.  Leaves above 31 primitives cannot be written that way and are always taken cooperatively.
+    const uint32_t n_esc = (uint32_t)__popcll(escm);
+    const bool coop = esc && (count > 31u || n_esc * (uint32_t)kCoopLanesPerPrim <= count);
+    if (esc && !coop) T.cur = kLeafBit | (count << kLeafCountShift) | first;
     unsigned long long todo = __ballot(coop);
     const uint32_t lane = threadIdx.x & 63u;
     while (todo) {

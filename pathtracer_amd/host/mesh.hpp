@@ -11,7 +11,16 @@
 // Material mapping, mesh.rs:39-66: dissolve < 1 -> Dielectric{1.0, 1.3, Ka}; else
 // Diffuse{speculaty: Ns, Kd}; no material -> backup_material.
 // mesh.rs indexes `normals[...]` unconditionally, so a face corner without a normal is an error
-// here (the reference panics).  Triangles come out in file order.
+// here (the reference panics).
+//
+// PARITY UNPINNED where it matters: mesh.rs:10-29 iterates tobj's `models` and pushes each model's
+// triangles in turn, so the ORDER of the Vec<Triangle> — which decides leaf order and therefore which
+// primitive wins a traversal — is tobj's model order.  This loader emits triangles in file
+// order, which equals tobj's order as long as tobj appends a model whenever an `o` / `g` / `usemtl`
+// statement closes the current one (its documented behaviour, restated in oracle/obj_ref.py).  The crate is
+// not under /root/reference and the reference holds no OBJ fixture or expected output, so that equivalence
+// — like every other tobj rule above — is restated from the crate's published behaviour, not checked
+// against it.
 #pragma once
 
 #include <cstdlib>

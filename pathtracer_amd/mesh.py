@@ -1,6 +1,9 @@
 """load_mesh of the reference (src/mesh.rs:9-73) for the Python host side: a minimal Wavefront
 OBJ / MTL reader producing the arrays PathTracer.set_triangles takes.  Same rules as
-pathtracer_amd/host/mesh.hpp (the C++ host mirror), which documents what is taken from tobj.
+pathtracer_amd/host/mesh.hpp (the C++ host mirror), which documents what is taken from tobj — and
+that parity with the tobj crate itself (in particular the order in which its models, and so the
+triangles, come out: mesh.rs:10-29) is UNPINNED: the crate is absent and the reference holds no
+OBJ fixture.
 Numbers go through Python's float() and are then rounded to f32; for inputs of up to 17
 significant digits that equals a direct correctly rounded f32 parse except on exact ties."""
 import os

@@ -3,7 +3,7 @@
 Every round draws a scene (soup / statue / spheres of random size and materials, sometimes with a
 specular floor or a speculaty > 1 material so that shadow rays run), a camera, an image size, a
 depth and a sample count, and compares BVH, 20 000 traces (closest and any), camera state, and
-the frame sums in both pt_render modes.  Stops at the first difference (exit code 1)."""
+the frame sums in both pt_render modes and as queued one-sample calls.  Stops at the first difference (exit code 1)."""
 import sys
 import time
 
@@ -84,6 +84,12 @@ def main():
                 g.render(spp, depth, seed=seed)
                 ok = ok and g.read_accum()[0].tobytes() == want.tobytes()
             ok = ok and g.read_rgb8().tobytes() == o.read_rgb8().tobytes()
+            # the same frame as queued one-sample calls (pt_render_async): overlapping launches, same sums
+            g.set_option(ptcore.OPT_RENDER_MODE, 1)
+            g.set_camera(co, ct, W, H)
+            for _ in range(spp):
+                g.render_async(1, depth, seed=seed)
+            ok = ok and g.read_accum()[0].tobytes() == want.tobytes()
             what += " %dx%d depth %d spp %d" % (W, H, depth, spp)
         g.close()
         o.close()

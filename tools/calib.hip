@@ -3,9 +3,10 @@
 //   gather64  one random 64-B record (4 x 16 B) per lane, every record of the table read exactly once,
 //             the access shape of k_path's node fetch           -> what FETCH_SIZE reports per gathered byte, and the
 //             rate at which HBM / Infinity Cache serve such gathers (the roof of the C5 soup)
-//   valu      independent fp32 adds / multiplies, 6 waves per SIMD   -> VALU wave-instruction issue peak
+//   valu      independent plain fp32 v_mul / v_add (inline asm), 6 waves per SIMD -> VALU wave-instruction issue peak
+//   valu_pk   the same with packed v_pk_mul_f32 / v_pk_add_f32 (two operations per lane per instruction)
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o tools/calib tools/calib.hip
-// Run:   tools/calib <stream|gather64|valu> [MiB] [reps] [noflush]   (one JSON line per repetition; also under rocprofv3 --pmc FETCH_SIZE)
+// Run:   tools/calib <stream|gather64|valu|valu_pk> [MiB] [reps] [noflush]   (one JSON line per repetition; also under rocprofv3 --pmc FETCH_SIZE)
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -48,17 +49,48 @@ __global__ __launch_bounds__(64) void k_gather64(const float4* __restrict__ tabl
     if (acc == 123.456f) out[0] = acc;
 }
 
+// Independent plain fp32 VALU instructions written as inline asm, so that the compiler can neither pack them into
+// v_pk_* pairs nor fold them: 8 accumulators x 16 = 128 wave instructions per iteration, alternately v_mul_f32 / v_add_f32.
 __global__ __launch_bounds__(64) void k_valu(uint32_t iters, float seed, float* __restrict__ out) {
     float a0 = seed + threadIdx.x, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+    const float m = 1.0000001f, c = 0.25f;
     for (uint32_t i = 0; i < iters; ++i) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {  // 16 x 8 = 128 independent VALU instructions per iteration
-            a0 = a0 * 1.0000001f; a1 = a1 + 0.5f; a2 = a2 * 0.9999999f; a3 = a3 + 0.25f;
-            a4 = a4 * 1.0000002f; a5 = a5 + 0.125f; a6 = a6 * 0.9999998f; a7 = a7 + 0.0625f;
+        for (int u = 0; u < 16; ++u) {
+            asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a0) : "v"(m));
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(a1) : "v"(c));
+            asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a2) : "v"(m));
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(a3) : "v"(c));
+            asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a4) : "v"(m));
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(a5) : "v"(c));
+            asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a6) : "v"(m));
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(a7) : "v"(c));
         }
     }
     const float s = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
     if (s == 123.456f) out[0] = s;
+}
+
+// the same with packed instructions (v_pk_mul_f32 / v_pk_add_f32: two fp32 operations per lane each)
+typedef float float2v __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(64) void k_valu_pk(uint32_t iters, float seed, float* __restrict__ out) {
+    float2v a0 = {seed + threadIdx.x, seed}, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+    const float2v m = {1.0000001f, 0.9999999f}, c = {0.25f, 0.125f};
+    for (uint32_t i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a0) : "v"(m));
+            asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a1) : "v"(c));
+            asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a2) : "v"(m));
+            asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a3) : "v"(c));
+            asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a4) : "v"(m));
+            asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a5) : "v"(c));
+            asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a6) : "v"(m));
+            asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a7) : "v"(c));
+        }
+    }
+    const float2v t = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+    if (t.x + t.y == 123.456f) out[0] = t.x;
 }
 
 int main(int argc, char** argv) {
@@ -72,17 +104,19 @@ int main(int argc, char** argv) {
     hipEvent_t a, b;
     CK(hipEventCreate(&a));
     CK(hipEventCreate(&b));
-    if (!std::strcmp(what, "valu")) {
+    if (!std::strcmp(what, "valu") || !std::strcmp(what, "valu_pk")) {
+        const bool pk = !std::strcmp(what, "valu_pk");
         const uint32_t iters = 20000, grid = 256 * 24;
         for (int r = 0; r < reps; ++r) {
             CK(hipEventRecord(a, 0));
-            hipLaunchKernelGGL(k_valu, dim3(grid), dim3(64), 0, 0, iters, 1.0f, out);
+            if (pk) hipLaunchKernelGGL(k_valu_pk, dim3(grid), dim3(64), 0, 0, iters, 1.0f, out);
+            else hipLaunchKernelGGL(k_valu, dim3(grid), dim3(64), 0, 0, iters, 1.0f, out);
             CK(hipEventRecord(b, 0));
             CK(hipEventSynchronize(b));
             float ms = 0;
             CK(hipEventElapsedTime(&ms, a, b));
             const double insts = (double)grid * iters * 128;
-            std::printf("{\"kernel\": \"valu\", \"waves\": %u, \"wave_insts\": %.0f, \"ms\": %.3f, \"g_wave_insts_per_s\": %.1f}\n", grid, insts, ms,
+            std::printf("{\"kernel\": \"%s\", \"waves\": %u, \"wave_insts\": %.0f, \"ms\": %.3f, \"g_wave_insts_per_s\": %.1f}\n", what, grid, insts, ms,
                         insts / (ms * 1e-3) / 1e9);
         }
         return 0;

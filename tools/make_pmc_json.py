@@ -27,6 +27,15 @@ def calib():
     stream, g_hbm, g_mall, valu = lines("stream.txt"), lines("gather_hbm.txt"), lines("gather_mall.txt"), lines("valu.txt")
     p_stream, p_hbm, p_mall, p_req = pmc("p_stream.json")[0], pmc("p_gather_hbm.json")[0], pmc("p_gather_mall.json")[0], pmc("p_gather_req.json")[0]
     p_valu, p_clk = pmc("p_valu.json")
+    p_valu_pk, p_pk_clk = pmc("p_valu_pk.json")
+    valu_pk = lines("valu_pk.txt")
+
+    def valu_entry(rows, p, clk, what):
+        ghz = clk["GRBM_GUI_ACTIVE"] / 8 / (clk["dur_ms"] * 1e6)
+        return {"what": what, "wave_insts": rows[0]["wave_insts"], "SQ_INSTS_VALU": p["SQ_INSTS_VALU"], "SQ_ACTIVE_INST_VALU": p["SQ_ACTIVE_INST_VALU"],
+                "best_ms": min(r["ms"] for r in rows), "g_wave_insts_per_s_best": max(r["g_wave_insts_per_s"] for r in rows),
+                "ms_under_pmc": p["dur_ms"], "clock_ghz_under_pmc": ghz,
+                "simd_cycles_per_wave_inst_under_pmc": 1024 * ghz / (p["SQ_INSTS_VALU"] / (p["dur_ms"] * 1e6))}
     best = lambda rows, k: max(r[k] for r in rows)
     out = {
         "how": "tools/calib.hip through tools/calib_r2.sh on one MI355X; FETCH_SIZE is reported in KiB",
@@ -40,14 +49,8 @@ def calib():
                                                      "FETCH_SIZE_bytes": p_mall["FETCH_SIZE"] * 1024,
                                                      "fetch_size_over_bytes": p_mall["FETCH_SIZE"] * 1024 / g_mall[0]["bytes_read"],
                                                      "g_requests_per_s": best(g_mall[1:], "gb_per_s") / 64},
-        "valu_issue": {"waves": valu[0]["waves"], "source_ops": valu[0]["wave_insts"], "best_ms": min(r["ms"] for r in valu),
-                       "SQ_INSTS_VALU": p_valu["SQ_INSTS_VALU"], "SQ_ACTIVE_INST_VALU": p_valu["SQ_ACTIVE_INST_VALU"],
-                       "note": "the compiler packs the 8 independent chains pairwise (v_pk_mul_f32 / v_pk_add_f32), so the launch issues half as many "
-                               "wave instructions as the source has operations; rates below use the counted instructions",
-                       "ms_under_pmc": p_valu["dur_ms"], "clock_ghz_under_pmc": p_clk["GRBM_GUI_ACTIVE"] / 8 / (p_clk["dur_ms"] * 1e6),
-                       "g_wave_insts_per_s_under_pmc": p_valu["SQ_INSTS_VALU"] / (p_valu["dur_ms"] * 1e6),
-                       "g_wave_insts_per_s_best": p_valu["SQ_INSTS_VALU"] / (min(r["ms"] for r in valu) * 1e6),
-                       "simd_cycles_per_wave_inst": 1024 * p_clk["GRBM_GUI_ACTIVE"] / 8 / (p_clk["dur_ms"] * 1e6) / (p_valu["SQ_INSTS_VALU"] / (p_valu["dur_ms"] * 1e6))},
+        "valu_issue_plain": valu_entry(valu, p_valu, p_clk, "independent v_mul_f32 / v_add_f32 (inline asm), 6144 waves = 6 per SIMD"),
+        "valu_issue_packed": valu_entry(valu_pk, p_valu_pk, p_pk_clk, "the same with v_pk_mul_f32 / v_pk_add_f32 (two fp32 operations per lane per instruction)"),
     }
     json.dump(out, open(os.path.join(DST, "r2_calib.json"), "w"), indent=1)
     return out
@@ -87,8 +90,9 @@ def main():
     if cal:
         table["_calibration"] = {"fabric_gather_peak_g_requests_per_s_infinity_cache": cal["gather_64B_records_infinity_cache_128MiB"]["g_requests_per_s"],
                                  "fabric_gather_peak_g_requests_per_s_hbm": cal["gather_64B_records_hbm_4GiB"]["g_requests_per_s"],
-                                 "valu_measured_g_wave_insts_per_s": cal["valu_issue"]["g_wave_insts_per_s_best"],
-                                 "valu_simd_cycles_per_wave_inst": cal["valu_issue"]["simd_cycles_per_wave_inst"],
+                                 "valu_plain_measured_g_wave_insts_per_s": cal["valu_issue_plain"]["g_wave_insts_per_s_best"],
+                                 "valu_plain_simd_cycles_per_wave_inst": cal["valu_issue_plain"]["simd_cycles_per_wave_inst_under_pmc"],
+                                 "valu_packed_simd_cycles_per_wave_inst": cal["valu_issue_packed"]["simd_cycles_per_wave_inst_under_pmc"],
                                  "source": "profiles/r2_calib.json"}
     json.dump(table, open(path, "w"), indent=1, sort_keys=True)
     print(json.dumps(table, indent=1)[:3000])
