@@ -26,8 +26,13 @@
 #define PT_HD static inline
 #endif
 
+#if defined(__cplusplus)
 PT_HD uint32_t pt_f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
 PT_HD float pt_u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+#else /* plain C hosts: type punning through a union is defined behaviour in C */
+PT_HD uint32_t pt_f2u(float f) { union { float f; uint32_t u; } c; c.f = f; return c.u; }
+PT_HD float pt_u2f(uint32_t u) { union { float f; uint32_t u; } c; c.u = u; return c.f; }
+#endif
 
 /* round-to-nearest-even to an integer-valued float, valid for |x| < 2^22; plain IEEE adds so
  * the result cannot depend on which rint implementation a compiler picks. */
