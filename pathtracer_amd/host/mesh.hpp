@@ -17,7 +17,7 @@
 // triangles in turn, so the ORDER of the Vec<Triangle> — which decides leaf order and therefore which
 // primitive wins a traversal — is tobj's model order.  This loader emits triangles in file
 // order, which equals tobj's order as long as tobj appends a model whenever an `o` / `g` / `usemtl`
-// statement closes the current one (its documented behaviour, restated in oracle/obj_ref.py).  The crate is
+// statement closes the current one (its documented behaviour, which the test suite restates independently).  The crate is
 // not under /root/reference and the reference holds no OBJ fixture or expected output, so that equivalence
 // — like every other tobj rule above — is restated from the crate's published behaviour, not checked
 // against it.

@@ -52,7 +52,7 @@ def test_detmath_compiled_as_c_gives_the_same_bits(tmp_path):
                    '    printf("%%08x %%08x %%08x %%08x %%08x\\n", pt_f2u(s), pt_f2u(c), pt_f2u(pt_expf(-xs[i] * xs[i])), pt_f2u(pt_acosf(xs[i] * 0.15f)), pt_f2u(pt_atan2f(xs[i], 1.5f - xs[i]))); }\n'
                    "  return 0; }\n" % (", ".join("%.9ef" % x for x in xs), len(xs)))
     exe = tmp_path / "dm"
-    r = subprocess.run(["gcc", "-std=c11", "-O2", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], capture_output=True, text=True)
+    r = subprocess.run(["gcc", "-std=c11", "-O2", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-lm"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     got = np.array([[int(w, 16) for w in ln.split()] for ln in subprocess.run([str(exe)], capture_output=True, text=True).stdout.splitlines()], np.uint32)
     want = np.stack([orc.math_fn(0, xs), orc.math_fn(1, xs), orc.math_fn(2, (-xs * xs).astype(np.float32)), orc.math_fn(3, (xs * np.float32(0.15)).astype(np.float32)),
