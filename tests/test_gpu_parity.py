@@ -919,8 +919,8 @@ def test_obj_scene_end_to_end_against_the_oracle_loader(ptcore, orc, sky, tmp_pa
     o = orc.from_scene(scenes.wrap_mesh(pos, nrm, np.array(ids, np.uint32), rows, floor_speculaty=0.5), sky)
     W, H = 96, 64
     o.set_camera(scenes.CAMERA_ORIGIN, scenes.CAMERA_TARGET, W, H)
-    for _ in range(3):
-        o.render(2, 32, seed=2026, nthreads=4, nee_mode=1)
+    for frame in range(3):
+        o.render(2, 32, seed=2026, sample_begin=2 * frame, nthreads=4, nee_mode=1)
     want = o.read_accum()[0]
     yy, xx = np.mgrid[0:H, 0:W]
     primary = o.trace(o.generate(np.stack([xx.ravel(), yy.ravel()], 1).astype(np.uint32), 0, 2026))
