@@ -139,6 +139,7 @@ extern "C" {
     pub fn pt_read_accum(ctx: *mut pt_ctx, rgb: *mut f32, spp_out: *mut f32) -> c_int;
     pub fn pt_write_accum(ctx: *mut pt_ctx, rgb: *const f32, spp: f32) -> c_int;
     pub fn pt_read_rgb8(ctx: *mut pt_ctx, rgb: *mut u8, pitch_bytes: u64) -> c_int;
+    pub fn pt_read_rgb8_latest(ctx: *mut pt_ctx, rgb: *mut u8, pitch_bytes: u64, spp_out: *mut f32) -> c_int;
     pub fn pt_accum_device_ptr(ctx: *mut pt_ctx, ptr: *mut *mut c_void, n_floats: *mut u64) -> c_int;
     pub fn pt_add_external_samples(ctx: *mut pt_ctx, spp: f32) -> c_int;
     pub fn pt_shard_slab_floats(width: u32, height: u32, tile: u32, rank: u32, nranks: u32, n_floats: *mut u64) -> c_int;

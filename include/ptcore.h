@@ -194,6 +194,14 @@ int pt_read_accum(pt_ctx *ctx, float *rgb, float *spp_out);
 int pt_write_accum(pt_ctx *ctx, const float *rgb, float spp);
 /* vec_to_rgb(scale * accum) (src/main.rs:71-75,160-164) into an RGB24 image with row pitch. */
 int pt_read_rgb8(pt_ctx *ctx, uint8_t *rgb, uint64_t pitch_bytes);
+/* The frame as far as it has got, without waiting for queued render calls (no counterpart in the reference, whose
+ * loop blocks on every frame): vec_to_rgb(accum / n) for the n samples that have been added so far — always whole
+ * calls' batches in submission order, so with one batch per call the image equals what pt_read_rgb8 would have
+ * returned after that many pt_render calls.  *spp_out = n (0 before the first batch has been added: the image is
+ * then undefined, as the reference's 1 / 0 scale would make it).  Waits only for accumulate kernels already on
+ * their way, never for a path kernel: a display loop can call pt_render_async + pt_read_rgb8_latest every
+ * iteration and keep the device busy. */
+int pt_read_rgb8_latest(pt_ctx *ctx, uint8_t *rgb, uint64_t pitch_bytes, float *spp_out);
 /* device address of the W x H x 3 float accumulator, for collectives that combine ranks. */
 int pt_accum_device_ptr(pt_ctx *ctx, void **ptr, uint64_t *n_floats);
 /* add `spp` to the sample count after an external reduce put other ranks' sums in accum. */

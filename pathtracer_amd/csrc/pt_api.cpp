@@ -143,7 +143,9 @@ struct pt_ctx {
     pt_camera_state cam{};
     bool have_cam = false;
     DevBuf d_accum;
-    float spp = 0.f;
+    DevBuf d_rgb;             // RGB24 staging of pt_read_rgb8 / pt_read_rgb8_latest (kept between calls)
+    float spp = 0.f;          // samples submitted (what the frame holds once everything queued has been added)
+    float spp_added = 0.f;    // samples whose k_accumulate has been enqueued on the accumulate stream so far
     uint32_t samples_done = 0;
 
     // pipeline
@@ -270,7 +272,7 @@ void pt_destroy(pt_ctx* c) {
     }
     if (c->acc_stream) (void)hipStreamDestroy(c->acc_stream);
     DevBuf* bufs[] = {&c->d_pairs, &c->d_prim, &c->d_meta, &c->d_nrm, &c->d_big, &c->d_mats, &c->d_sky, &c->d_lights, &c->d_cam,
-                      &c->d_accum, &c->d_spill, &c->d_counters};
+                      &c->d_accum, &c->d_rgb, &c->d_spill, &c->d_counters};
     for (DevBuf* b : bufs) b->release();
     for (RenderLane& L : c->lanes) {
         DevBuf* lb[] = {&L.d_ro, &L.d_rd, &L.d_hit, &L.d_tp, &L.d_out, &L.d_acc, &L.d_pxs, &L.d_q0, &L.d_q1, &L.d_qn, &L.d_spill};
@@ -585,7 +587,7 @@ int pt_reset_accum(pt_ctx* c) {
     PT_HIP(c, hipSetDevice(c->device));
     PT_HIP(c, hipMemsetAsync(c->d_accum.p, 0, (size_t)c->cam.width * c->cam.height * 3 * sizeof(float), c->stream));
     PT_HIP(c, hipStreamSynchronize(c->stream));
-    c->spp = 0.f;
+    c->spp = c->spp_added = 0.f;
     c->samples_done = 0;
     return PT_OK;
 }
@@ -848,6 +850,7 @@ static int lane_accumulate(pt_ctx* c, RenderLane& L, RenderJob& J) {
     launch_accumulate(J.M, L.ps.out, L.ns, c->opt_render_mode == 1, (float*)c->d_accum.p, c->acc_stream);
     PT_HIP(c, hipEventRecord(L.ev_done, c->acc_stream));
     PT_HIP(c, hipGetLastError());
+    c->spp_added += (float)L.ns;
     L.state = RenderLane::DRAINING;
     return PT_OK;
 }
@@ -903,6 +906,7 @@ static int abort_jobs(pt_ctx* c, int rc) {
     }
     S.jobs.clear();
     S.acc_seq = S.next_seq;
+    c->spp = c->spp_added;  // the frame holds what was added before the failure
     for (RenderLane& L : c->lanes) {
         L.state = RenderLane::IDLE;
         L.job = nullptr;
@@ -1065,6 +1069,7 @@ int pt_render_async(pt_ctx* c, uint32_t spp, uint32_t max_depth, uint64_t seed, 
     pixelmap_init(M, M.width, M.height, M.tile, M.rank, M.nranks);
     if (M.npix_pad == 0) {  // this rank owns no tile
         c->spp += (float)spp;
+        c->spp_added += (float)spp;
         c->samples_done = sample_begin + spp;
         return PT_OK;
     }
@@ -1138,8 +1143,24 @@ int pt_write_accum(pt_ctx* c, const float* rgb, float spp) {
     if (int rc = drain(c)) return rc;
     PT_HIP(c, hipSetDevice(c->device));
     PT_HIP(c, hipMemcpy(c->d_accum.p, rgb, (size_t)c->cam.width * c->cam.height * 3 * sizeof(float), hipMemcpyHostToDevice));
-    c->spp = spp;
+    c->spp = c->spp_added = spp;
     c->samples_done = (uint32_t)spp;
+    return PT_OK;
+}
+
+// vec_to_rgb(accum / spp) on the accumulate stream, behind every k_accumulate enqueued so far, into caller memory
+static int resolve_to_host(pt_ctx* c, uint8_t* rgb, uint64_t pitch, float spp, const char* who) {
+    PT_HIP(c, hipSetDevice(c->device));
+    int rc = dev_alloc(c, c->d_rgb, (size_t)pitch * c->cam.height);
+    if (rc) return rc;
+    const float scale = 1.0f / spp;  // main.rs:145
+    launch_resolve((const float*)c->d_accum.p, c->cam.width, c->cam.height, scale, (uint8_t*)c->d_rgb.p, pitch, c->acc_stream);
+    hipError_t e = hipGetLastError();
+    // only the 3 * width payload bytes of each row are written; the caller's padding is left alone
+    if (e == hipSuccess)
+        e = hipMemcpy2DAsync(rgb, pitch, c->d_rgb.p, pitch, (size_t)c->cam.width * 3, c->cam.height, hipMemcpyDeviceToHost, c->acc_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->acc_stream);
+    if (e != hipSuccess) return c->fail(PT_ERR_HIP, std::string(who) + ": " + hipGetErrorString(e));
     return PT_OK;
 }
 
@@ -1148,19 +1169,21 @@ int pt_read_rgb8(pt_ctx* c, uint8_t* rgb, uint64_t pitch) {
     if (!c->have_cam) return c->fail(PT_ERR_STATE, "pt_read_rgb8: no camera");
     if (!rgb || pitch < (uint64_t)c->cam.width * 3) return c->fail(PT_ERR_INVALID, "pt_read_rgb8: null pointer or pitch < 3 * width");
     if (int rc = drain(c)) return rc;
-    PT_HIP(c, hipSetDevice(c->device));
-    DevBuf d;
-    int rc = dev_alloc(c, d, (size_t)pitch * c->cam.height);
-    if (rc) return rc;
-    const float scale = 1.0f / c->spp;  // main.rs:145
-    launch_resolve((const float*)c->d_accum.p, c->cam.width, c->cam.height, scale, (uint8_t*)d.p, pitch, c->stream);
-    hipError_t e = hipStreamSynchronize(c->stream);
-    // only the 3 * width payload bytes of each row are written; the caller's padding is left alone
-    if (e == hipSuccess)
-        e = hipMemcpy2D(rgb, pitch, d.p, pitch, (size_t)c->cam.width * 3, c->cam.height, hipMemcpyDeviceToHost);
-    d.release();
-    if (e != hipSuccess) return c->fail(PT_ERR_HIP, std::string("pt_read_rgb8: ") + hipGetErrorString(e));
-    return PT_OK;
+    return resolve_to_host(c, rgb, pitch, c->spp, "pt_read_rgb8");
+}
+
+int pt_read_rgb8_latest(pt_ctx* c, uint8_t* rgb, uint64_t pitch, float* spp_out) {
+    if (!c) return PT_ERR_INVALID;
+    if (!c->have_cam) return c->fail(PT_ERR_STATE, "pt_read_rgb8_latest: no camera");
+    if (!rgb || pitch < (uint64_t)c->cam.width * 3) return c->fail(PT_ERR_INVALID, "pt_read_rgb8_latest: null pointer or pitch < 3 * width");
+    if (!c->sched->jobs.empty()) {  // let finished launches be added, start queued ones; never waits for a path kernel
+        PT_HIP(c, hipSetDevice(c->device));
+        bool progressed = false;
+        int rc = pump_once(c, progressed);
+        if (rc) return abort_jobs(c, rc);
+    }
+    if (spp_out) *spp_out = c->spp_added;
+    return resolve_to_host(c, rgb, pitch, c->spp_added, "pt_read_rgb8_latest");
 }
 
 int pt_accum_device_ptr(pt_ctx* c, void** ptr, uint64_t* n_floats) {
@@ -1176,6 +1199,7 @@ int pt_add_external_samples(pt_ctx* c, float spp) {
     if (!c) return PT_ERR_INVALID;
     if (int rc = drain(c)) return rc;
     c->spp += spp;
+    c->spp_added += spp;
     return PT_OK;
 }
 

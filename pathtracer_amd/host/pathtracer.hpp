@@ -228,6 +228,12 @@ public:
     void wait() { detail::check(ctx_, pt_wait(ctx_), "pt_wait"); }
     // vec_to_rgb(scale * accum) into an RGB24 buffer with SDL-style pitch, src/main.rs:160-164
     void rgb24(uint8_t* buffer, size_t pitch) { detail::check(ctx_, pt_read_rgb8(ctx_, buffer, pitch), "pt_read_rgb8"); }
+    // the frame as far as it has got, without waiting for queued frames; returns the samples it holds (pt_read_rgb8_latest)
+    float rgb24_latest(uint8_t* buffer, size_t pitch) {
+        float spp = 0.f;
+        detail::check(ctx_, pt_read_rgb8_latest(ctx_, buffer, pitch, &spp), "pt_read_rgb8_latest");
+        return spp;
+    }
     float accum(std::vector<float>& rgb) {
         rgb.resize((size_t)width_ * height_ * 3);
         float spp = 0;

@@ -9,7 +9,8 @@
 //              after each step as hex float bits (changed, origin, target, direction, right, up, p1, p2, p3, focal distance)
 // --input-check  device-free check of the key arithmetic: reads lines "<15 hex words: origin target direction right up>
 //              <depth> <keys>" from stdin, prints "<changed> <6 hex words: origin target> <depth>" per line
-// --async      queue the frames with render_async and wait once at the end (frames overlap on the device)
+// --async      queue the frames with render_async, show the latest complete state every iteration (rgb24_latest) and wait once
+//              at the end (frames overlap on the device; same final image)
 #include <iostream>
 #include <sstream>
 #include <chrono>
@@ -138,7 +139,8 @@ static int run(Camera<T>& camera, uint32_t W, uint32_t H, int frames, int spp, c
     auto t0 = std::chrono::steady_clock::now();
     for (int f = 0; f < frames; ++f) {
         if (af.async) {
-            camera.render_async(spp, 32, 2026);  // queued: the frame is shown when it has been added
+            camera.render_async(spp, 32, 2026);              // queued: frames overlap on the device ...
+            camera.rgb24_latest(fb.data(), (size_t)W * 3);   // ... and the window shows the frame as far as it has got
         } else {
             camera.render(spp, 32, 2026);   // spp += 1 per frame in the reference, main.rs:143
             camera.rgb24(fb.data(), (size_t)W * 3);

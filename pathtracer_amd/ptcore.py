@@ -37,7 +37,7 @@ OPT_BATCH_PATHS, OPT_LANES, OPT_TAIL_MIN_PATHS, OPT_TAIL_FRACTION, OPT_TAIL_STRE
 EXPORTS = [
     "pt_strerror", "pt_last_error", "pt_create", "pt_destroy", "pt_set_triangles", "pt_set_spheres", "pt_set_materials",
     "pt_set_sky", "pt_build", "pt_set_bvh", "pt_bvh_build", "pt_get_bvh_sizes", "pt_get_bvh", "pt_set_camera", "pt_get_camera", "pt_generate", "pt_render", "pt_render_async", "pt_wait",
-    "pt_shard_map", "pt_shard_slab_floats", "pt_shard_pack", "pt_shard_unpack", "pt_reset_accum", "pt_read_accum", "pt_write_accum", "pt_read_rgb8", "pt_accum_device_ptr", "pt_add_external_samples", "pt_trace", "pt_trace_noalloc",
+    "pt_shard_map", "pt_shard_slab_floats", "pt_shard_pack", "pt_shard_unpack", "pt_reset_accum", "pt_read_accum", "pt_write_accum", "pt_read_rgb8", "pt_read_rgb8_latest", "pt_accum_device_ptr", "pt_add_external_samples", "pt_trace", "pt_trace_noalloc",
     "pt_sample_skybox", "pt_set_option", "pt_get_counters", "pt_get_round_stats", "pt_reset_counters",
 ]
 
@@ -280,6 +280,14 @@ class PathTracer:
         out = np.zeros((self.height, pitch), dtype=np.uint8)
         self._ck(self.l.pt_read_rgb8(self.h, _ptr(out), C.c_uint64(pitch)))
         return out[:, : self.width * 3].reshape(self.height, self.width, 3)
+
+    def read_rgb8_latest(self, pitch=None):
+        """(image, samples added so far) without waiting for queued render calls (pt_read_rgb8_latest)."""
+        pitch = pitch or self.width * 3
+        out = np.zeros((self.height, pitch), dtype=np.uint8)
+        spp = C.c_float()
+        self._ck(self.l.pt_read_rgb8_latest(self.h, _ptr(out), C.c_uint64(pitch), C.byref(spp)))
+        return out[:, : self.width * 3].reshape(self.height, self.width, 3), spp.value
 
     def accum_device_ptr(self):
         p, n = C.c_void_p(), C.c_uint64()

@@ -945,3 +945,32 @@ def test_obj_scene_end_to_end_against_the_oracle_loader(ptcore, orc, sky, tmp_pa
     raw = np.fromfile(acc, np.uint8)
     assert raw[8:12].view(np.float32)[0] == 6.0
     assert raw[12:].tobytes() == want.tobytes()
+
+
+def test_latest_frame_without_waiting(ptcore, pairs):
+    """pt_read_rgb8_latest: while one-sample calls are queued, the image of the n samples added so far is the
+    reference's frame after n iterations of its loop (main.rs:143-170) — n never goes back, every image equals the
+    oracle's tonemapped frame for that n, and after pt_wait it is the final frame."""
+    g, o, scene, cam_o, cam_t = pairs["mesh_20k"]
+    W, H, frames = 160, 96, 10
+    o.set_camera(cam_o, cam_t, W, H)
+    want = {}
+    for k in range(1, frames + 1):
+        o.render(1, 32, seed=31, sample_begin=k - 1, nthreads=8, nee_mode=1)
+        want[k] = o.read_rgb8().copy()
+    g.set_camera(cam_o, cam_t, W, H)
+    seen, last = set(), 0
+    for _ in range(frames):
+        g.render_async(1, 32, seed=31)
+        img, n = g.read_rgb8_latest()
+        assert n == int(n) and last <= n <= frames
+        last = int(n)
+        if last:
+            np.testing.assert_array_equal(img, want[last])
+            seen.add(last)
+    g.wait()
+    img, n = g.read_rgb8_latest(pitch=W * 3 + 32)
+    assert n == frames
+    np.testing.assert_array_equal(img, want[frames])
+    np.testing.assert_array_equal(g.read_rgb8(), want[frames])
+    assert g.read_accum()[1] == frames
