@@ -144,6 +144,7 @@ struct pt_ctx {
     bool have_cam = false;
     DevBuf d_accum;
     DevBuf d_rgb;             // RGB24 staging of pt_read_rgb8 / pt_read_rgb8_latest (kept between calls)
+    DevBuf d_stage_in, d_stage_out;  // device copies of the seams' inputs / outputs (pt_trace, pt_generate, pt_sample_skybox); grow only
     float spp = 0.f;          // samples submitted (what the frame holds once everything queued has been added)
     float spp_added = 0.f;    // samples whose k_accumulate has been enqueued on the accumulate stream so far
     uint32_t samples_done = 0;
@@ -272,7 +273,7 @@ void pt_destroy(pt_ctx* c) {
     }
     if (c->acc_stream) (void)hipStreamDestroy(c->acc_stream);
     DevBuf* bufs[] = {&c->d_pairs, &c->d_prim, &c->d_meta, &c->d_nrm, &c->d_big, &c->d_mats, &c->d_sky, &c->d_lights, &c->d_cam,
-                      &c->d_accum, &c->d_rgb, &c->d_spill, &c->d_counters};
+                      &c->d_accum, &c->d_rgb, &c->d_stage_in, &c->d_stage_out, &c->d_spill, &c->d_counters};
     for (DevBuf* b : bufs) b->release();
     for (RenderLane& L : c->lanes) {
         DevBuf* lb[] = {&L.d_ro, &L.d_rd, &L.d_hit, &L.d_tp, &L.d_out, &L.d_acc, &L.d_pxs, &L.d_q0, &L.d_q1, &L.d_qn, &L.d_spill};
@@ -598,17 +599,14 @@ int pt_generate(pt_ctx* c, const uint32_t* xy, uint64_t n, uint32_t sample, uint
     if (n == 0) return PT_OK;
     if (!xy || !rays) return c->fail(PT_ERR_INVALID, "pt_generate: null pointer");
     PT_HIP(c, hipSetDevice(c->device));
-    DevBuf dxy, dr;
     int rc;
-    if ((rc = dev_upload(c, dxy, xy, n * 8))) return rc;
-    if ((rc = dev_alloc(c, dr, n * sizeof(pt_ray)))) { dxy.release(); return rc; }
-    launch_generate((const DevCamera*)c->d_cam.p, (const uint32_t*)dxy.p, n, sample, (uint32_t)seed, (uint32_t)(seed >> 32), (pt_ray*)dr.p,
-                    c->stream);
-    hipError_t e = hipStreamSynchronize(c->stream);
-    if (e == hipSuccess) e = hipMemcpy(rays, dr.p, n * sizeof(pt_ray), hipMemcpyDeviceToHost);
-    dxy.release();
-    dr.release();
-    if (e != hipSuccess) return c->fail(PT_ERR_HIP, std::string("pt_generate: ") + hipGetErrorString(e));
+    if ((rc = dev_upload(c, c->d_stage_in, xy, n * 8))) return rc;
+    if ((rc = dev_alloc(c, c->d_stage_out, n * sizeof(pt_ray)))) return rc;
+    launch_generate((const DevCamera*)c->d_cam.p, (const uint32_t*)c->d_stage_in.p, n, sample, (uint32_t)seed, (uint32_t)(seed >> 32),
+                    (pt_ray*)c->d_stage_out.p, c->stream);
+    PT_HIP(c, hipGetLastError());
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    PT_HIP(c, hipMemcpy(rays, c->d_stage_out.p, n * sizeof(pt_ray), hipMemcpyDeviceToHost));
     return PT_OK;
 }
 
@@ -618,18 +616,14 @@ int pt_trace(pt_ctx* c, const pt_ray* rays, uint64_t n, int any_hit, pt_hit* hit
     if (n == 0) return PT_OK;
     if (!rays || !hits) return c->fail(PT_ERR_INVALID, "pt_trace: null pointer");
     PT_HIP(c, hipSetDevice(c->device));
-    DevBuf dr, dh;
     int rc;
-    if ((rc = dev_upload(c, dr, rays, n * sizeof(pt_ray)))) return rc;
-    if ((rc = dev_alloc(c, dh, n * sizeof(pt_hit)))) { dr.release(); return rc; }
-    launch_trace(c->prim_kind, any_hit != 0, true, c->ds, (const pt_ray*)dr.p, n, (pt_hit*)dh.p, c->cfg,
+    if ((rc = dev_upload(c, c->d_stage_in, rays, n * sizeof(pt_ray)))) return rc;
+    if ((rc = dev_alloc(c, c->d_stage_out, n * sizeof(pt_hit)))) return rc;
+    launch_trace(c->prim_kind, any_hit != 0, true, c->ds, (const pt_ray*)c->d_stage_in.p, n, (pt_hit*)c->d_stage_out.p, c->cfg,
                  (unsigned long long*)c->d_counters.p, c->stream);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e == hipSuccess) e = hipMemcpy(hits, dh.p, n * sizeof(pt_hit), hipMemcpyDeviceToHost);
-    dr.release();
-    dh.release();
-    if (e != hipSuccess) return c->fail(PT_ERR_HIP, std::string("pt_trace: ") + hipGetErrorString(e));
+    PT_HIP(c, hipGetLastError());
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    PT_HIP(c, hipMemcpy(hits, c->d_stage_out.p, n * sizeof(pt_hit), hipMemcpyDeviceToHost));
     return PT_OK;
 }
 
@@ -672,16 +666,13 @@ int pt_sample_skybox(pt_ctx* c, const float* dirs, uint64_t n, float* rgb) {
     if (n == 0) return PT_OK;
     if (!dirs || !rgb) return c->fail(PT_ERR_INVALID, "pt_sample_skybox: null pointer");
     PT_HIP(c, hipSetDevice(c->device));
-    DevBuf dd, dc;
     int rc;
-    if ((rc = dev_upload(c, dd, dirs, n * 12))) return rc;
-    if ((rc = dev_alloc(c, dc, n * 12))) { dd.release(); return rc; }
-    launch_sky(c->ds, (const float*)dd.p, n, (float*)dc.p, c->stream);
-    hipError_t e = hipStreamSynchronize(c->stream);
-    if (e == hipSuccess) e = hipMemcpy(rgb, dc.p, n * 12, hipMemcpyDeviceToHost);
-    dd.release();
-    dc.release();
-    if (e != hipSuccess) return c->fail(PT_ERR_HIP, std::string("pt_sample_skybox: ") + hipGetErrorString(e));
+    if ((rc = dev_upload(c, c->d_stage_in, dirs, n * 12))) return rc;
+    if ((rc = dev_alloc(c, c->d_stage_out, n * 12))) return rc;
+    launch_sky(c->ds, (const float*)c->d_stage_in.p, n, (float*)c->d_stage_out.p, c->stream);
+    PT_HIP(c, hipGetLastError());
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    PT_HIP(c, hipMemcpy(rgb, c->d_stage_out.p, n * 12, hipMemcpyDeviceToHost));
     return PT_OK;
 }
 
