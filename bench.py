@@ -37,6 +37,8 @@ Extra objects on the JSON line:
 import argparse
 import json
 import os
+
+import numpy as np
 import subprocess
 import sys
 import time
@@ -63,6 +65,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-replay", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the spp sweep and the C1 entry")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearsal of the N > 1 path on ONE GPU (all ranks on device 0, collectives staged through the host)")
+    ap.add_argument("--verify", action="store_true", help="rank 0 re-renders the combined frame alone (untimed) and compares")
     return ap.parse_args()
 
 
@@ -220,10 +225,13 @@ def main():
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
-    if use_dist:
+    one_gpu = args.backend == "gloo"   # rehearsal: every rank on device 0
+    if use_dist and one_gpu:
+        dist.init_process_group("gloo")
+    elif use_dist:
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    device = local_rank if use_dist else 0
+    device = local_rank if use_dist and not one_gpu else 0
     torch.cuda.set_device(device)
 
     make, W, H, cam_o, cam_t, desc = workloads(scenes)[args.workload]
@@ -234,7 +242,7 @@ def main():
     g.set_option(ptcore.OPT_RENDER_MODE, 1 if args.mode == "path" else 0)
     seed = 2026
     spp = args.spp
-    tiles = args.shard == "tiles" and world > 1
+    tiles = args.shard == "tiles" and use_dist   # also with one rank under the launcher: pack, gather, un-swizzle all run
 
     def shard_for(step):
         if tiles:   # this rank's tiles, every sample of the step
@@ -289,8 +297,9 @@ def main():
         # warm the collective too (communicator channels and buffers for this message size are set up on first use)
         if tiles:
             ptdist.gather_tiles(g)
-        else:
+        elif not one_gpu:
             dist.reduce(torch.zeros(H, W, 3, dtype=torch.float32, device=f"cuda:{device}"), dst=0, op=dist.ReduceOp.SUM)
+    g.reset_accum()   # the combined frame holds exactly the timed steps' samples (the warm-up's are dropped on every rank)
     g.reset_counters()
     barrier()
     t0 = time.perf_counter()
@@ -302,16 +311,32 @@ def main():
     rays = c["rays_closest"] + c["rays_any"]
     paths = c["paths"]
 
-    tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{device}")
-    work = torch.tensor([rays, paths], dtype=torch.float64, device=f"cuda:{device}")
+    stat_dev = "cpu" if one_gpu else f"cuda:{device}"
+    tt = torch.tensor([dt], dtype=torch.float64, device=stat_dev)
+    work = torch.tensor([rays, paths], dtype=torch.float64, device=stat_dev)
     if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(work, op=dist.ReduceOp.SUM)
     dt_max = float(tt.item())
     rays_all, paths_all = float(work[0].item()), float(work[1].item())
 
+    verified = None
+    if args.verify and rank == 0:
+        # the combined frame against the same samples rendered by this rank alone
+        got, got_spp = g.read_accum()
+        g.reset_accum()
+        if tiles:   # every rank rendered all samples of its tiles: the frame holds steps x spp samples, bit-identical
+            for s_ in range(args.warmup, args.warmup + args.steps):
+                g.render(spp, args.depth, seed, ptcore.Shard(ptcore.SHARD_ALL, 0, 1, 0, s_ * spp))
+            want = g.read_accum()[0]
+            verified = bool(got.tobytes() == want.tobytes() and got_spp == args.steps * spp)
+        else:       # rank r of step s rendered samples [(s * world + r) * spp, ...): summed in another order -> fp32 tolerance
+            for s_ in range(args.warmup, args.warmup + args.steps):
+                g.render(spp * world, args.depth, seed, ptcore.Shard(ptcore.SHARD_ALL, 0, 1, 0, s_ * world * spp))
+            want = g.read_accum()[0]
+            verified = bool(np.allclose(got, want, rtol=2e-5, atol=1e-6) and got_spp == args.steps * spp * world)
     if rank == 0:
-        if world == 1:
+        if world == 1 and not tiles:
             par = "1 GPU"
         elif tiles:
             par = f"tile-sharded x{world} (64x64 tiles round-robin), one gather of tile slabs at readout"
@@ -327,6 +352,10 @@ def main():
             "rays_per_path": rays_all / max(paths_all, 1),
             "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
         }
+        if one_gpu:
+            out["rehearsal"] = f"{world} ranks on ONE GPU over gloo (collectives staged through the host): a functional check, not a scaling number"
+        if verified is not None:
+            out["verified"] = verified
         k_ms = c["tail_ms"] if args.mode == "path" else c["extend_ms"]          # time with >= 1 launch running
         k_ms_sum = c["tail_ms_sum"] if args.mode == "path" else c["extend_ms_sum"]  # sum of launch durations
         launches = max(c["tail_launches"] if args.mode == "path" else c["extend_launches"], 1)

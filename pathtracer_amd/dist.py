@@ -23,6 +23,13 @@ import torch.distributed as dist
 
 from . import ptcore
 
+if ptcore._lib is not None and not ptcore._torch_first:
+    # torch ships its own HIP runtime (torch/lib/libamdhip64.so); libptcore.so binds to whichever copy the process
+    # loaded first.  Loaded before torch it pulls in /opt/rocm's copy, torch then brings a second one, and the second
+    # runtime in a process finds no GPU ("No HIP GPUs are available").  Loaded after torch, both share torch's copy.
+    raise ImportError("pathtracer_amd.dist: libptcore.so was loaded before torch was imported; import torch (or "
+                      "pathtracer_amd.dist) before the first pathtracer_amd.ptcore call so both share one HIP runtime")
+
 TILE = 64  # edge of the tiles dealt round-robin to ranks
 
 
@@ -56,9 +63,20 @@ def slab_pixel_index(width, height, tile, rank, nranks) -> np.ndarray:
     return np.where((x < width) & (y < height), y * width + x, -1)
 
 
+def _host_staged() -> bool:
+    """gloo has no device-side reduce / gather: ranks that rehearse the N > 1 path on one GPU (bench.py --backend gloo,
+    tests) stage the collective through host memory.  The production backend is nccl (RCCL), device to device."""
+    return dist.get_backend() == "gloo"
+
+
 def gather_slabs(slab: torch.Tensor, dst: int = 0):
     """ONE gather of equally sized slabs to `dst`; returns the list of slabs there (None elsewhere)."""
     world, rank = dist.get_world_size(), dist.get_rank()
+    if slab.is_cuda and _host_staged():
+        host = slab.cpu()
+        parts = [torch.empty_like(host) for _ in range(world)] if rank == dst else None
+        dist.gather(host, parts, dst=dst)
+        return [p.to(slab.device) for p in parts] if rank == dst else None
     parts = [torch.empty_like(slab) for _ in range(world)] if rank == dst else None
     dist.gather(slab, parts, dst=dst)
     return parts
@@ -69,7 +87,13 @@ def reduce_samples(pt: ptcore.PathTracer, spp_of_other_ranks: float, dst: int = 
     memory) and tell `dst` how many samples the others contributed."""
     dev = torch.device("cuda", torch.cuda.current_device())
     acc = torch.as_tensor(ptcore.AccumView(pt), device=dev)  # waits for queued render calls
-    dist.reduce(acc, dst=dst, op=dist.ReduceOp.SUM)
+    if _host_staged():
+        host = acc.cpu()
+        dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
+        if dist.get_rank() == dst:
+            acc.copy_(host)
+    else:
+        dist.reduce(acc, dst=dst, op=dist.ReduceOp.SUM)
     torch.cuda.synchronize()
     if dist.get_rank() == dst:
         pt.add_external_samples(spp_of_other_ranks)

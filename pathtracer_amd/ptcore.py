@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -78,6 +79,7 @@ class PtError(RuntimeError):
 
 
 _lib = None
+_torch_first = True  # False when libptcore.so was loaded into a process that had not imported torch yet (see dist.py)
 
 
 def load() -> C.CDLL:
@@ -87,6 +89,8 @@ def load() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: build it with `make -C pathtracer_amd/csrc` "
                               "(or __graft_entry__.build()); there is no CPU fallback")
+        global _torch_first
+        _torch_first = "torch" in sys.modules
         lib = C.CDLL(os.environ.get("PTCORE_LIB", LIB_PATH))  # PTCORE_LIB: A/B builds of the same ABI
         lib.pt_strerror.restype = C.c_char_p
         lib.pt_last_error.restype = C.c_char_p

@@ -852,6 +852,34 @@ def test_nccl_leg_world_size_one(ptcore, pairs):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("shard", ["samples", "tiles"])
+def test_bench_two_ranks_rehearsed_on_one_gpu(shard):
+    """bench.py --gpus 2 end to end, as the driver launches it, with both ranks on THIS GPU and gloo in place of RCCL
+    (collectives staged through the host): rank arithmetic, sample / tile shards, the combine, the spp bookkeeping and
+    the one JSON line.  --verify: rank 0 re-renders the combined frame alone; tiles must match bit for bit, sample
+    shards to fp32 summation-order tolerance."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--workload", "tiny", "--spp", "4", "--shard", shard, "--backend", "gloo", "--verify"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["verified"] is True
+    assert out["scaling"] == ("strong" if shard == "tiles" else "weak")
+    paths = 256 * 144 * 4 * 2 * (1 if shard == "tiles" else 2)   # tiles: the two ranks split each step's frame
+    assert round(out["mpaths_per_s"] * out["ms_per_step"] * 2 * 1e3) == pytest.approx(paths, rel=1e-6)
+
+
 def test_handle_input_through_the_cpp_host(orc, sky, tmp_path):
     """Camera::handle_input (camera.rs:114-212) end to end in the C++ host mirror: key sets -> origin / target ->
     Camera::update on the device (autofocus included).  `render --keys` prints the pose after every step; the
