@@ -171,12 +171,14 @@ def c1_entry(ptcore, scenes, sky, device):
                            "kind": "port", "frames": frames,
                            "note": "oracle in the reference's threading mode (static row bands, shadow rays traced as the reference does)"},
                    "gpu": {"mrays_per_s": (gc["rays_closest"] + gc["rays_any"]) / gdt / 1e6, "mpaths_per_s": gc["paths"] / gdt / 1e6,
-                           "fps": gframes / gdt, "frames": gframes, "note": "1-spp calls queued with pt_render_async, one wait at the end"}}}
+                           "fps": gframes / gdt, "frames": gframes, "launches": gc["tail_launches"],
+                           "note": "1-spp calls queued with pt_render_async, one wait at the end; calls queued behind busy lanes are merged into larger launches"}}}
 
 
 def spp_sweep(g, ptcore, W, H, depth, seed):
     """Mrays/s against samples per call: queued calls (pt_render_async + one pt_wait) and, for 1 spp, blocking calls
-    (the reference's loop shows every frame: main.rs:143-175)."""
+    (the reference's loop shows every frame: main.rs:143-175).  Calls queued while every lane is busy are merged into
+    larger launches by the library (PT_OPT_MERGE_QUEUED_CALLS, same results); `launches` says how many there were."""
     out = {}
     for spp, calls in ((1, 64), (8, 16), (64, 8)):
         g.reset_accum()
@@ -190,7 +192,8 @@ def spp_sweep(g, ptcore, W, H, depth, seed):
         g.wait()
         dt = time.perf_counter() - t0
         c = g.counters()
-        out[f"{spp}_spp_per_call_queued"] = {"mrays_per_s": (c["rays_closest"] + c["rays_any"]) / dt / 1e6, "ms_per_call": dt * 1e3 / calls, "calls": calls}
+        out[f"{spp}_spp_per_call_queued"] = {"mrays_per_s": (c["rays_closest"] + c["rays_any"]) / dt / 1e6, "ms_per_call": dt * 1e3 / calls, "calls": calls,
+                                             "launches": c["tail_launches"]}  # fewer than calls: queued calls that had not started were merged
     g.reset_accum()
     g.render(1, depth, seed)
     g.reset_counters()

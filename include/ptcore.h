@@ -250,9 +250,13 @@ int pt_sample_skybox(pt_ctx *ctx, const float *dirs, uint64_t n, float *rgb);
  *  PT_OPT_FIRST_CHECK_ROUND  rounds enqueued before the live-path count is first looked at (default 3)
  *  PT_OPT_TAIL_MODE       0 = fused phase-scheduled tail kernel, 1 = further rounds on the tail stream with a small
  *                         grid, 2 = fused tail kernel that traces and shades in lock step
- *  PT_OPT_SIMPLE_EXTEND   1 = one-ray-per-lane traversal kernel instead of the persistent one (A/B, tests) */
+ *  PT_OPT_SIMPLE_EXTEND   1 = one-ray-per-lane traversal kernel instead of the persistent one (A/B, tests)
+ *  PT_OPT_MERGE_QUEUED_CALLS  a pt_render_async call that continues the newest queued call (same frame, depth, seed,
+ *                         shard and flags, the next sample indices) while that call has not started yet is added to it, up
+ *                         to this many paths per merged call (default 128 Mi; 0 = never merge).  Same results, fewer and
+ *                         larger launches when calls arrive faster than they are rendered */
 enum { PT_OPT_BATCH_PATHS = 0, PT_OPT_LANES = 1, PT_OPT_TAIL_MIN_PATHS = 2, PT_OPT_TAIL_FRACTION = 3,
-       PT_OPT_TAIL_STREAMS = 4, PT_OPT_TAIL_PATHS_PER_LANE = 5, PT_OPT_SIMPLE_EXTEND = 6, PT_OPT_BULK_STREAMS = 7, PT_OPT_TAIL_MODE = 8, PT_OPT_FIRST_CHECK_ROUND = 9, PT_OPT_RENDER_MODE = 10 };
+       PT_OPT_TAIL_STREAMS = 4, PT_OPT_TAIL_PATHS_PER_LANE = 5, PT_OPT_SIMPLE_EXTEND = 6, PT_OPT_BULK_STREAMS = 7, PT_OPT_TAIL_MODE = 8, PT_OPT_FIRST_CHECK_ROUND = 9, PT_OPT_RENDER_MODE = 10, PT_OPT_MERGE_QUEUED_CALLS = 11 };
 int pt_set_option(pt_ctx *ctx, int option, uint64_t value);
 int pt_get_counters(pt_ctx *ctx, pt_counters *out);
 /* Diagnostics of the wavefront loop (no counterpart in the reference): after a pt_render with

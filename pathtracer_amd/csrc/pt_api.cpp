@@ -38,6 +38,7 @@ constexpr uint32_t kMaxDepth = 0xffffu;        // iteration counter has 16 bits
 constexpr uint64_t kTargetSlots = 8u << 20;    // wavefront mode: paths kept in flight per batch (about 8.4 M, 112 B of state each)
 constexpr uint64_t kPathBatchSlots = 512u << 20;  // path-kernel mode: paths per launch (16 B each); measured: the larger the better
 constexpr uint64_t kMaxSlots = 1ull << 31;
+constexpr uint64_t kMergeSlots = 128ull << 20;  // queued calls are merged up to this many paths (64 spp at 1080p: ~25 ms a launch)
 constexpr uint32_t kMaxLanes = 8;              // batches in flight (one HIP stream + path-state set each)
 constexpr uint64_t kTailMinPaths = 65536;      // hand a batch to the fused tail kernel below this many live paths ...
 constexpr uint64_t kTailFraction = 16;         // ... or below 1/16 of the batch
@@ -162,7 +163,8 @@ struct pt_ctx {
     DevBuf d_counters;
     double render_ms = 0;
     uint64_t extend_launches = 0, tail_launches = 0;
-    uint64_t opt_batch_slots = 0 /* 0 = the mode's default */, opt_tail_min = kTailMinPaths, opt_tail_fraction = kTailFraction, opt_lanes = 0 /* 0 = the mode's default */, opt_tail_streams = 4, opt_tail_paths_per_lane = 4, opt_first_check = 3, opt_simple_extend = 0, opt_bulk_streams = kMaxLanes, opt_tail_mode = 0, opt_render_mode = 1;
+    uint64_t opt_batch_slots = 0 /* 0 = the mode's default */, opt_tail_min = kTailMinPaths, opt_tail_fraction = kTailFraction, opt_lanes = 0 /* 0 = the mode's default */, opt_tail_streams = 4, opt_tail_paths_per_lane = 4, opt_first_check = 3, opt_simple_extend = 0, opt_bulk_streams = kMaxLanes, opt_tail_mode = 0, opt_render_mode = 1, opt_merge_calls = kMergeSlots;
+    uint64_t merged_calls = 0;  // pt_render_async calls that were added to a queued call instead of becoming a launch of their own
     std::vector<uint32_t> round_sizes;  // queue length of every round of the last finished batch
 
     int fail(int code, const std::string& msg) {
@@ -1023,6 +1025,38 @@ static int drain(pt_ctx* c) {
     return PT_OK;
 }
 
+// Cut a call's J.spp samples into batches of whole samples and size what depends on the batch.
+static int plan_batches(pt_ctx* c, RenderJob& J) {
+    const PixelMap& M = J.M;
+    const uint64_t want_slots = c->opt_batch_slots ? c->opt_batch_slots : (c->opt_render_mode == 1 ? kPathBatchSlots : kTargetSlots);
+    uint64_t per_batch = std::max<uint64_t>(1, want_slots / M.npix_pad);
+    per_batch = std::min<uint64_t>(per_batch, J.spp);
+    if (per_batch * M.npix_pad >= kMaxSlots) return c->fail(PT_ERR_LIMIT, "pt_render: batch too large");
+    J.per_batch = per_batch;
+    J.batch_slots = per_batch * M.npix_pad;
+    J.n_batches = (uint32_t)((J.spp + per_batch - 1) / per_batch);
+    // path-kernel mode: launches in flight cover each other's ends (a launch ends with a few long paths in nearly empty
+    // waves).  Small batches (few samples per call) are mostly end, so up to eight of them overlap (C3: 1 spp per call
+    // 0.76 -> 1.25 Grays/s, 8 spp 4.2 -> 6.6, 64 spp 10.3 -> 10.8 with 2 -> 8 in flight); every launch in flight holds a
+    // radiance slab of 16 B per path, so large batches stay at two (more measured no faster there): the slabs of all
+    // lanes together are kept under 24 GiB.  The wavefront rounds need all eight.
+    uint64_t want_lanes = c->opt_lanes;
+    if (!want_lanes) want_lanes = c->opt_render_mode == 1 ? std::min<uint64_t>(kMaxLanes, std::max<uint64_t>(2, (24ull << 30) / (J.batch_slots * 16))) : kMaxLanes;
+    J.max_lanes = (uint32_t)want_lanes;
+    J.tail_threshold = c->opt_tail_fraction == 0 ? 0 : (uint32_t)std::max<uint64_t>(c->opt_tail_min, J.batch_slots / c->opt_tail_fraction);
+    return PT_OK;
+}
+
+// A call that continues the newest queued call (same frame parameters, the next sample indices) while that one has
+// not started a batch yet — every lane is busy with earlier calls — is added to it: a host that submits 1 sample per
+// call faster than the GPU renders them then gets launches of many samples (which run an order of magnitude more
+// rays per second than launches of one) instead of a growing queue of small ones.  Results do not
+// change: a sample is a function of (pixel, global sample index, seed) and sums are built in sample order either way.
+static bool same_frame(const RenderJob& a, const RenderJob& b) {
+    return a.M.width == b.M.width && a.M.height == b.M.height && a.M.tile == b.M.tile && a.M.rank == b.M.rank && a.M.nranks == b.M.nranks &&
+           a.max_depth == b.max_depth && a.k0 == b.k0 && a.k1 == b.k1 && a.timed == b.timed && a.count == b.count;
+}
+
 int pt_render_async(pt_ctx* c, uint32_t spp, uint32_t max_depth, uint64_t seed, const pt_shard* shard, uint32_t flags) {
     if (!c) return PT_ERR_INVALID;
     if (!c->built) return c->fail(PT_ERR_STATE, "pt_render: scene changed since pt_build (or never built): call pt_build first");
@@ -1065,21 +1099,6 @@ int pt_render_async(pt_ctx* c, uint32_t spp, uint32_t max_depth, uint64_t seed, 
         return PT_OK;
     }
 
-    const uint64_t want_slots = c->opt_batch_slots ? c->opt_batch_slots : (c->opt_render_mode == 1 ? kPathBatchSlots : kTargetSlots);
-    uint64_t per_batch = std::max<uint64_t>(1, want_slots / M.npix_pad);
-    per_batch = std::min<uint64_t>(per_batch, spp);
-    if (per_batch * M.npix_pad >= kMaxSlots) return c->fail(PT_ERR_LIMIT, "pt_render: batch too large");
-    J.per_batch = per_batch;
-    J.batch_slots = per_batch * M.npix_pad;
-    J.n_batches = (uint32_t)((spp + per_batch - 1) / per_batch);
-    // path-kernel mode: launches in flight cover each other's ends (a launch ends with a few long paths in nearly empty
-    // waves).  Small batches (few samples per call) are mostly end, so up to eight of them overlap (C3: 1 spp per call
-    // 0.76 -> 1.25 Grays/s, 8 spp 4.2 -> 6.6, 64 spp 10.3 -> 10.8 with 2 -> 8 in flight); every launch in flight holds a
-    // radiance slab of 16 B per path, so large batches stay at two (more measured no faster there): the slabs of all
-    // lanes together are kept under 24 GiB.  The wavefront rounds need all eight.
-    uint64_t want_lanes = c->opt_lanes;
-    if (!want_lanes) want_lanes = c->opt_render_mode == 1 ? std::min<uint64_t>(kMaxLanes, std::max<uint64_t>(2, (24ull << 30) / (J.batch_slots * 16))) : kMaxLanes;
-    J.max_lanes = (uint32_t)want_lanes;
     J.spp = spp;
     J.sample_begin = sample_begin;
     J.max_depth = max_depth;
@@ -1088,7 +1107,24 @@ int pt_render_async(pt_ctx* c, uint32_t spp, uint32_t max_depth, uint64_t seed, 
     J.k1 = (uint32_t)(seed >> 32);
     J.timed = (flags & PT_RENDER_TIMED) != 0;
     J.count = (flags & PT_RENDER_COUNT) != 0;
-    J.tail_threshold = c->opt_tail_fraction == 0 ? 0 : (uint32_t)std::max<uint64_t>(c->opt_tail_min, J.batch_slots / c->opt_tail_fraction);
+    if (c->opt_merge_calls && !S.jobs.empty()) {
+        RenderJob& B = S.jobs.back();
+        if (B.next_batch == 0 && same_frame(B, J) && (uint64_t)B.sample_begin + B.spp == sample_begin && ((uint64_t)B.spp + spp) * B.M.npix_pad <= c->opt_merge_calls) {
+            RenderJob merged = B;  // planned on a copy: a failure leaves the queued call as it was
+            merged.spp = B.spp + spp;
+            if (int rc = plan_batches(c, merged)) return rc;
+            S.next_seq = B.seq0 + merged.n_batches;  // B is the newest call, so its batches are the last in the order
+            B = std::move(merged);
+            c->spp += (float)spp;
+            c->samples_done = sample_begin + spp;
+            c->merged_calls += 1;
+            bool progressed = false;
+            int rc = pump_once(c, progressed);
+            if (rc) return abort_jobs(c, rc);
+            return PT_OK;
+        }
+    }
+    if (int rc = plan_batches(c, J)) return rc;
     J.seq0 = S.next_seq;
     J.t0 = std::chrono::steady_clock::now();
     if (J.timed && !S.ev_epoch) {
@@ -1258,6 +1294,7 @@ int pt_set_option(pt_ctx* c, int option, uint64_t value) {
         case PT_OPT_RENDER_MODE: c->opt_render_mode = value; return PT_OK;
         case PT_OPT_TAIL_MODE: c->opt_tail_mode = value; return PT_OK;
         case PT_OPT_SIMPLE_EXTEND: c->opt_simple_extend = value; return PT_OK;
+        case PT_OPT_MERGE_QUEUED_CALLS: c->opt_merge_calls = std::min<uint64_t>(value, kMaxSlots - 1); return PT_OK;
         case PT_OPT_TAIL_PATHS_PER_LANE: c->opt_tail_paths_per_lane = std::max<uint64_t>(value, 1); return PT_OK;
         default: return c->fail(PT_ERR_INVALID, "pt_set_option: unknown option");
     }

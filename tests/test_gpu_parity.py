@@ -765,6 +765,48 @@ def test_queued_calls_equal_blocking_calls(ptcore, pairs, name):
         g.set_option(ptcore.OPT_LANES, 0)
 
 
+def test_queued_calls_are_merged_while_the_lanes_are_busy(ptcore, pairs):
+    """pt_render_async adds a call to the newest queued call when that one has not started yet and the new call
+    continues it (PT_OPT_MERGE_QUEUED_CALLS): fewer, larger launches, the same bits.  With the option at 0 every call
+    is a launch of its own; a cap of three samples' paths bounds every merged call."""
+    g, o, scene, cam_o, cam_t = pairs["mesh_20k"]
+    W, H = 256, 160
+    calls = 24
+    g.set_camera(cam_o, cam_t, W, H)
+    for _ in range(calls):
+        g.render(1, 32, seed=9)
+    want = g.read_accum()[0]
+    try:
+        g.set_option(ptcore.OPT_LANES, 2)
+        launches = {}
+        for cap in (0, 3 * W * H, 128 << 20):
+            g.set_option(ptcore.OPT_MERGE_QUEUED_CALLS, cap)
+            g.set_camera(cam_o, cam_t, W, H)
+            g.reset_counters()
+            for _ in range(calls):
+                g.render_async(1, 32, seed=9)
+            acc, spp = g.read_accum()
+            assert spp == float(calls) and acc.tobytes() == want.tobytes(), cap
+            c = g.counters()
+            assert c["paths"] == calls * W * H
+            launches[cap] = c["tail_launches"]
+        assert launches[0] == calls
+        assert calls // 3 <= launches[3 * W * H] < calls
+        assert launches[128 << 20] < launches[3 * W * H]
+        # a call that does not continue the queued one (other seed, a gap in the sample indices) is never merged
+        g.set_camera(cam_o, cam_t, W, H)
+        g.reset_counters()
+        for i in range(6):
+            g.render_async(1, 32, seed=9, shard=ptcore.Shard(ptcore.SHARD_ALL, 0, 1, 0, 2 * i))
+        for i in range(6):
+            g.render_async(1, 32, seed=10 + i)
+        g.wait()
+        assert g.counters()["tail_launches"] == 12
+    finally:
+        g.set_option(ptcore.OPT_LANES, 0)
+        g.set_option(ptcore.OPT_MERGE_QUEUED_CALLS, 128 << 20)
+
+
 def test_timed_counters_union_and_sum(ptcore, pairs):
     """PT_RENDER_TIMED: tail_ms is the time during which at least one k_path launch ran, tail_ms_sum the plain
     sum; with several batches in flight the sum exceeds the union, with one lane they agree."""
