@@ -3,7 +3,7 @@
 Every round draws a scene (soup / statue / spheres of random size and materials, sometimes with a
 specular floor or a speculaty > 1 material so that shadow rays run), a camera, an image size, a
 depth and a sample count, and compares BVH, 20 000 traces (closest and any), camera state, and
-the frame sums in both pt_render modes and as queued one-sample calls.  Stops at the first difference (exit code 1)."""
+the frame sums in both pt_render modes and as queued one-sample calls (few and many, merged under a random cap).  Stops at the first difference (exit code 1)."""
 import sys
 import time
 
@@ -90,7 +90,19 @@ def main():
             for _ in range(spp):
                 g.render_async(1, depth, seed=seed)
             ok = ok and g.read_accum()[0].tobytes() == want.tobytes()
-            what += " %dx%d depth %d spp %d" % (W, H, depth, spp)
+            # many queued calls behind few lanes: the library merges those that have not started (random cap); against
+            # one blocking call of as many samples
+            calls = int(rng.integers(6, 30))
+            g.set_camera(co, ct, W, H)
+            g.render(calls, depth, seed=seed)
+            whole = g.read_accum()[0]
+            g.set_option(ptcore.OPT_LANES, int(rng.integers(1, 4)))
+            g.set_option(ptcore.OPT_MERGE_QUEUED_CALLS, int(rng.choice([0, 2 * W * H, 5 * W * H, 128 << 20])))
+            g.set_camera(co, ct, W, H)
+            for _ in range(calls):
+                g.render_async(1, depth, seed=seed)
+            ok = ok and g.read_accum()[0].tobytes() == whole.tobytes()
+            what += " %dx%d depth %d spp %d, %d queued calls" % (W, H, depth, spp, calls)
         g.close()
         o.close()
         rounds += 1
