@@ -194,6 +194,24 @@ def spp_sweep(g, ptcore, W, H, depth, seed):
         c = g.counters()
         out[f"{spp}_spp_per_call_queued"] = {"mrays_per_s": (c["rays_closest"] + c["rays_any"]) / dt / 1e6, "ms_per_call": dt * 1e3 / calls, "calls": calls,
                                              "launches": c["tail_launches"]}  # fewer than calls: queued calls that had not started were merged
+    # the reference's frame loop with the display decoupled: one sample submitted and the newest finished frame fetched
+    # as RGB24 (over PCIe, into a reused texture buffer) per iteration, without waiting for the queued launches
+    texture = np.zeros((H, W * 3), dtype=np.uint8)
+    for timed in (False, True):
+        g.reset_accum()
+        g.reset_counters()
+        frames = 200
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            g.render_async(1, depth, seed)
+            _, shown = g.read_rgb8_latest(out=texture)
+        t_loop = time.perf_counter() - t0
+        g.wait()
+        dt = time.perf_counter() - t0
+    c = g.counters()
+    out["1_spp_per_frame_with_rgb_readout"] = {"mrays_per_s": (c["rays_closest"] + c["rays_any"]) / dt / 1e6, "frames_shown_per_s": frames / t_loop,
+                                               "frames": frames, "launches": c["tail_launches"], "samples_in_the_last_frame_shown": shown,
+                                               "note": "pt_render_async(1 spp) + pt_read_rgb8_latest per iteration: PCIe readout of every shown frame included"}
     g.reset_accum()
     g.render(1, depth, seed)
     g.reset_counters()

@@ -144,6 +144,8 @@ struct pt_ctx {
     pt_camera_state cam{};
     bool have_cam = false;
     DevBuf d_accum;
+    uint8_t* h_rgb = nullptr; // pinned host staging of the same readouts (kept between calls)
+    size_t h_rgb_bytes = 0;
     DevBuf d_rgb;             // RGB24 staging of pt_read_rgb8 / pt_read_rgb8_latest (kept between calls)
     DevBuf d_stage_in, d_stage_out;  // device copies of the seams' inputs / outputs (pt_trace, pt_generate, pt_sample_skybox); grow only
     float spp = 0.f;          // samples submitted (what the frame holds once everything queued has been added)
@@ -244,9 +246,15 @@ int pt_create(int device, pt_ctx** out) {
         return PT_ERR_HIP;
     }
     c->sched = new pt_sched();
-    if (hipStreamCreateWithFlags(&c->acc_stream, hipStreamNonBlocking) != hipSuccess) {
-        pt_destroy(c);
-        return PT_ERR_HIP;
+    {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        // highest priority: accumulates and frame readouts are short kernels that must not queue behind the path
+        // kernels' workgroups (and streams of another priority do not share a hardware queue with the launch streams)
+        if (hipStreamCreateWithPriority(&c->acc_stream, hipStreamNonBlocking, hi) != hipSuccess) {
+            pt_destroy(c);
+            return PT_ERR_HIP;
+        }
     }
     if (dev_alloc(c, c->d_counters, CNT_N * sizeof(unsigned long long)) != PT_OK ||
         hipMemset(c->d_counters.p, 0, CNT_N * sizeof(unsigned long long)) != hipSuccess) {
@@ -277,6 +285,7 @@ void pt_destroy(pt_ctx* c) {
     DevBuf* bufs[] = {&c->d_pairs, &c->d_prim, &c->d_meta, &c->d_nrm, &c->d_big, &c->d_mats, &c->d_sky, &c->d_lights, &c->d_cam,
                       &c->d_accum, &c->d_rgb, &c->d_stage_in, &c->d_stage_out, &c->d_spill, &c->d_counters};
     for (DevBuf* b : bufs) b->release();
+    if (c->h_rgb) (void)hipHostFree(c->h_rgb);
     for (RenderLane& L : c->lanes) {
         DevBuf* lb[] = {&L.d_ro, &L.d_rd, &L.d_hit, &L.d_tp, &L.d_out, &L.d_acc, &L.d_pxs, &L.d_q0, &L.d_q1, &L.d_qn, &L.d_spill};
         for (DevBuf* b : lb) b->release();
@@ -1184,10 +1193,25 @@ static int resolve_to_host(pt_ctx* c, uint8_t* rgb, uint64_t pitch, float spp, c
     launch_resolve((const float*)c->d_accum.p, c->cam.width, c->cam.height, scale, (uint8_t*)c->d_rgb.p, pitch, c->acc_stream);
     hipError_t e = hipGetLastError();
     // only the 3 * width payload bytes of each row are written; the caller's padding is left alone
-    if (e == hipSuccess)
-        e = hipMemcpy2DAsync(rgb, pitch, c->d_rgb.p, pitch, (size_t)c->cam.width * 3, c->cam.height, hipMemcpyDeviceToHost, c->acc_stream);
+    // Through pinned staging memory: a copy straight into the caller's pageable rows (hipMemcpy2DAsync) measured 7.4 ms
+    // for a 1080p frame, 0.8 GB/s.  Only the 3 * width payload bytes of each row reach the caller; its padding is left alone.
+    const size_t bytes = (size_t)pitch * c->cam.height;
+    if (e == hipSuccess && c->h_rgb_bytes < bytes) {
+        if (c->h_rgb) (void)hipHostFree(c->h_rgb);
+        c->h_rgb = nullptr;
+        c->h_rgb_bytes = 0;
+        e = hipHostMalloc((void**)&c->h_rgb, bytes, hipHostMallocDefault);
+        if (e == hipSuccess) c->h_rgb_bytes = bytes;
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(c->h_rgb, c->d_rgb.p, bytes, hipMemcpyDeviceToHost, c->acc_stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->acc_stream);
     if (e != hipSuccess) return c->fail(PT_ERR_HIP, std::string(who) + ": " + hipGetErrorString(e));
+    const size_t row = (size_t)c->cam.width * 3;
+    if (pitch == row) {
+        std::memcpy(rgb, c->h_rgb, bytes);
+    } else {
+        for (uint32_t y = 0; y < c->cam.height; ++y) std::memcpy(rgb + (size_t)y * pitch, c->h_rgb + (size_t)y * pitch, row);
+    }
     return PT_OK;
 }
 

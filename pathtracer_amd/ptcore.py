@@ -285,10 +285,14 @@ class PathTracer:
         self._ck(self.l.pt_read_rgb8(self.h, _ptr(out), C.c_uint64(pitch)))
         return out[:, : self.width * 3].reshape(self.height, self.width, 3)
 
-    def read_rgb8_latest(self, pitch=None):
-        """(image, samples added so far) without waiting for queued render calls (pt_read_rgb8_latest)."""
+    def read_rgb8_latest(self, pitch=None, out=None):
+        """(image, samples added so far) without waiting for queued render calls (pt_read_rgb8_latest).
+        `out`: a (height, pitch) uint8 array to fill instead of a new one (a frame loop reuses its texture buffer)."""
         pitch = pitch or self.width * 3
-        out = np.zeros((self.height, pitch), dtype=np.uint8)
+        if out is None:
+            out = np.zeros((self.height, pitch), dtype=np.uint8)
+        elif out.dtype != np.uint8 or out.shape != (self.height, pitch) or not out.flags.c_contiguous:
+            raise ValueError("read_rgb8_latest: out must be a C-contiguous (height, pitch) uint8 array")
         spp = C.c_float()
         self._ck(self.l.pt_read_rgb8_latest(self.h, _ptr(out), C.c_uint64(pitch), C.byref(spp)))
         return out[:, : self.width * 3].reshape(self.height, self.width, 3), spp.value
