@@ -198,7 +198,7 @@ int pt_read_rgb8(pt_ctx *ctx, uint8_t *rgb, uint64_t pitch_bytes);
  * loop blocks on every frame): vec_to_rgb(accum / n) for the n samples that have been added so far — always whole
  * calls' batches in submission order, so with one batch per call the image equals what pt_read_rgb8 would have
  * returned after that many pt_render calls.  *spp_out = n (0 before the first batch has been added: the image is
- * then undefined, as the reference's 1 / 0 scale would make it).  Waits only for accumulate kernels already on
+ * then black).  Merged queued calls (PT_OPT_MERGE_QUEUED_CALLS) are added as one, so n advances by their sum.  Waits only for accumulate kernels already on
  * their way, never for a path kernel: a display loop can call pt_render_async + pt_read_rgb8_latest every
  * iteration and keep the device busy. */
 int pt_read_rgb8_latest(pt_ctx *ctx, uint8_t *rgb, uint64_t pitch_bytes, float *spp_out);

@@ -1234,6 +1234,10 @@ int pt_read_rgb8_latest(pt_ctx* c, uint8_t* rgb, uint64_t pitch, float* spp_out)
         if (rc) return abort_jobs(c, rc);
     }
     if (spp_out) *spp_out = c->spp_added;
+    if (c->spp_added == 0.f) {  // nothing has been added yet (the first launch is still running): a black frame, not 0 / 0
+        for (uint32_t y = 0; y < c->cam.height; ++y) std::memset(rgb + (size_t)y * pitch, 0, (size_t)c->cam.width * 3);
+        return PT_OK;
+    }
     return resolve_to_host(c, rgb, pitch, c->spp_added, "pt_read_rgb8_latest");
 }
 

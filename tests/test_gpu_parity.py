@@ -1038,6 +1038,8 @@ def test_latest_frame_without_waiting(ptcore, pairs):
         if last:
             np.testing.assert_array_equal(img, want[last])
             seen.add(last)
+        else:
+            assert not img.any()   # nothing added yet: black, not 0 / 0
     g.wait()
     img, n = g.read_rgb8_latest(pitch=W * 3 + 32)
     assert n == frames
