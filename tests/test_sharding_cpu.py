@@ -118,3 +118,21 @@ def test_two_rank_gloo_shards_reassemble(tmp_path):
     assert r["gathered"].tobytes() == r["full"].tobytes()  # gather of compact slabs + un-swizzle: the same frame
     # sample shards are summed in a different order than the single frame loop: fp32 tolerance
     np.testing.assert_allclose(r["samples"], r["full"], rtol=1e-6, atol=1e-7)
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """bench.py --gpus N without a launcher starts N ranks itself and must fail (exit code 2, nothing launched) when
+    fewer than N devices are visible — here none is."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "GPU(s) visible" in r.stderr
+    # under a launcher whose WORLD_SIZE disagrees with --gpus the bench refuses as well
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr
