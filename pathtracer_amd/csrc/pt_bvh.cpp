@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <limits>
 #include <thread>
 
@@ -36,7 +37,8 @@ struct Box {
     }
 };
 
-// Parallel loop over [first, last) in contiguous pieces, one per thread (used on large nodes only).
+// Parallel loop over [first, last) in contiguous pieces, one per thread (used on large ranges only).  The pieces depend
+// only on (first, last, threads), so consecutive passes over one range see the same pieces.
 template <class F>
 void parallel_pieces(uint32_t first, uint32_t last, int threads, F&& body) {
     const uint32_t n = last - first;
@@ -54,20 +56,38 @@ void parallel_pieces(uint32_t first, uint32_t last, int threads, F&& body) {
     for (std::thread& th : pool) th.join();
 }
 
+int default_threads() {
+    const char* env = std::getenv("PTCORE_BUILD_THREADS");
+    int threads = env ? std::atoi(env) : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    return threads < 1 ? 1 : threads;
+}
+
+// A primitive as the build moves it around: bvh.indices[i] together with that object's centre and bounds, so that
+// every pass over a node reads its range of one array front to back (the reference looks each object up through
+// bvh.indices; following the indices into the object array made every pass a random gather).
+struct Rec {
+    float c[3], mn[3], mx[3];
+    uint32_t idx;
+};
+static_assert(sizeof(Rec) == 40, "record layout");
+
+constexpr uint32_t kParallelNode = 1u << 16;  // nodes of at least this many primitives are split by all threads of their subtree
+
 // One subtree, built in the reference's order.  `nodes` is local to the subtree: nodes[0] is a copy
 // of the subtree's root and child links are local indices, so subtrees can be built by different
 // threads and spliced together afterwards (the reference's explicit stack finishes a node's whole
 // subtree before it touches anything else, so a subtree's nodes are contiguous in its numbering).
-// `indices` is the shared bvh.indices array; a subtree only touches its own range of it.
+// `work`, `tmp` and `lpos` are arrays shared by all subtrees; a subtree only touches its own range of them.
 struct Builder {
-    const std::vector<PrimInfo>& prims;
-    uint32_t* indices;
+    Rec* work;
+    Rec* tmp;
+    uint32_t* lpos;
     std::vector<pt_bvh_node> nodes;
     uint32_t max_depth = 1;  // levels below and including this subtree's root
     bool hazard = false;
     int threads = 1;         // helper threads for the passes over one large node
 
-    Builder(const std::vector<PrimInfo>& p, uint32_t* idx) : prims(p), indices(idx) {}
+    Builder(Rec* w, Rec* t, uint32_t* l) : work(w), tmp(t), lpos(l) {}
 
     // bvh.rs:104-169.  Returns false when no split beats the parent cost.
     bool choose_split(const pt_bvh_node& node, int* axis_out, float* pivot_out) const {
@@ -77,12 +97,12 @@ struct Builder {
         const float parent_cost = nb.area() * (float)count;
 
         // min / max / counts are order independent, so the pieces of a large node can be reduced in any order
-        const int nt = threads > 1 && count >= (1u << 16) ? threads : 1;
+        const int nt = threads > 1 && count >= kParallelNode ? threads : 1;
         std::vector<Box> cbs((size_t)nt);
         parallel_pieces(first, first + count, nt, [&](int t, uint32_t a, uint32_t b) {
             Box cb;
             cb.clear();
-            for (uint32_t i = a; i < b; ++i) cb.grow_point(prims[indices[i]].c);
+            for (uint32_t i = a; i < b; ++i) cb.grow_point(work[i].c);
             cbs[(size_t)t] = cb;
         });
         Box cb = cbs[0];
@@ -99,7 +119,7 @@ struct Builder {
             Bins& B = parts[(size_t)t];
             for (int b = 0; b < 24; ++b) { B.box[b].clear(); B.n[b] = 0; }
             for (uint32_t i = a0; i < b0; ++i) {
-                const PrimInfo& p = prims[indices[i]];
+                const Rec& p = work[i];
                 for (int a = 0; a < 3; ++a) {
                     // ((c - cmin) / delta).max(0.).min(7.) as usize  — NaN (0/0) becomes 0
                     float q = (p.c[a] - cb.lo[a]) / delta[a];
@@ -148,7 +168,63 @@ struct Builder {
         return true;
     }
 
-    // bvh.rs:63-103.  The swap sequence decides the leaf order, so this pass stays sequential.
+    // The reference's partition (bvh.rs:63-103) walks the node once and swaps every object that belongs to the left
+    // with the object at the running split position.  The swap sequence decides the leaf order, so the result must be
+    // exactly that permutation — but it need not be produced by swapping.  Positions relative to the node, nL objects
+    // on the left, l[k] = original position of the k-th of them:
+    //   * the k-th left object ends at position k (the walk keeps their order);
+    //   * [split, i) only ever holds right objects, and event k (the walk reaching l[k]) moves the object standing at
+    //     position k to position l[k].  So a right object at position p stays if p >= nL, otherwise it moves to l[p]
+    //     (> p), and from there again while its position is below nL.
+    // Every object's final place follows from the flags and l[] alone: three passes that all threads share.
+    void partition_large(uint32_t first, uint32_t count, int axis, float pivot, Box& lb, Box& rb, uint32_t& n_left) {
+        const int nt = threads;
+        std::vector<uint32_t> base((size_t)nt + 1, 0);
+        std::vector<Box> lbs((size_t)nt), rbs((size_t)nt);
+        parallel_pieces(first, first + count, nt, [&](int t, uint32_t a, uint32_t b) {
+            Box l, r;
+            l.clear();
+            r.clear();
+            uint32_t nl = 0;
+            for (uint32_t i = a; i < b; ++i) {
+                const Rec& p = work[i];
+                if (p.c[axis] <= pivot) { l.grow(p.mn, p.mx); nl += 1; }
+                else r.grow(p.mn, p.mx);
+            }
+            lbs[(size_t)t] = l;
+            rbs[(size_t)t] = r;
+            base[(size_t)t + 1] = nl;
+        });
+        lb.clear();
+        rb.clear();
+        for (int t = 0; t < nt; ++t) {
+            lb.grow(lbs[(size_t)t].lo, lbs[(size_t)t].hi);
+            rb.grow(rbs[(size_t)t].lo, rbs[(size_t)t].hi);
+            base[(size_t)t + 1] += base[(size_t)t];
+        }
+        const uint32_t nL = base[(size_t)nt];
+        n_left = nL;
+        parallel_pieces(first, first + count, nt, [&](int t, uint32_t a, uint32_t b) {
+            uint32_t k = base[(size_t)t];
+            for (uint32_t i = a; i < b; ++i)
+                if (work[i].c[axis] <= pivot) lpos[first + k++] = i - first;
+        });
+        parallel_pieces(first, first + count, nt, [&](int t, uint32_t a, uint32_t b) {
+            uint32_t k = base[(size_t)t];
+            for (uint32_t i = a; i < b; ++i) {
+                const Rec& p = work[i];
+                if (p.c[axis] <= pivot) {
+                    tmp[first + k++] = p;
+                } else {
+                    uint32_t q = i - first;
+                    while (q < nL) q = lpos[first + q];
+                    tmp[first + q] = p;
+                }
+            }
+        });
+        parallel_pieces(first, first + count, nt, [&](int, uint32_t a, uint32_t b) { std::memcpy(work + a, tmp + a, (size_t)(b - a) * sizeof(Rec)); });
+    }
+
     bool partition(uint32_t ni) {
         int axis;
         float pivot;
@@ -156,27 +232,31 @@ struct Builder {
         if (!choose_split(node, &axis, &pivot)) return false;
         const uint32_t first = node.left_first, count = node.count;
         Box lb, rb;
-        lb.clear();
-        rb.clear();
-        uint32_t split = first;
-        for (uint32_t i = first; i < first + count; ++i) {
-            const PrimInfo& p = prims[indices[i]];
-            if (p.c[axis] <= pivot) {
-                lb.grow(p.mn, p.mx);
-                uint32_t tmp = indices[split];
-                indices[split] = indices[i];
-                indices[i] = tmp;
-                split += 1;
-            } else {
-                rb.grow(p.mn, p.mx);
+        uint32_t nl = 0;
+        if (threads > 1 && count >= kParallelNode) {
+            partition_large(first, count, axis, pivot, lb, rb, nl);
+        } else {
+            lb.clear();
+            rb.clear();
+            uint32_t split = first;
+            for (uint32_t i = first; i < first + count; ++i) {
+                const Rec p = work[i];
+                if (p.c[axis] <= pivot) {
+                    lb.grow(p.mn, p.mx);
+                    work[i] = work[split];
+                    work[split] = p;
+                    split += 1;
+                } else {
+                    rb.grow(p.mn, p.mx);
+                }
             }
+            nl = split - first;
         }
         const uint32_t left = (uint32_t)nodes.size();
         nodes[ni].left_first = left;
         nodes[ni].count = 0;
-        const uint32_t nl = split - first;
         nodes.push_back(pt_bvh_node{{lb.lo[0], lb.lo[1], lb.lo[2]}, first, {lb.hi[0], lb.hi[1], lb.hi[2]}, nl});
-        nodes.push_back(pt_bvh_node{{rb.lo[0], rb.lo[1], rb.lo[2]}, split, {rb.hi[0], rb.hi[1], rb.hi[2]}, count - nl});
+        nodes.push_back(pt_bvh_node{{rb.lo[0], rb.lo[1], rb.lo[2]}, first + nl, {rb.hi[0], rb.hi[1], rb.hi[2]}, count - nl});
         if (nl == 0 || nl == count) hazard = true;
         return true;
     }
@@ -207,7 +287,7 @@ constexpr uint32_t kParallelMin = 8192;  // smaller subtrees are not worth a thr
 
 // Builds the subtree below `root` with up to `threads` threads.  Result: b.nodes[0] = root, then
 // the subtree's nodes in the reference's order with local child links.
-void build_subtree(const std::vector<PrimInfo>& prims, uint32_t* indices, const pt_bvh_node& root, int threads, Builder& b) {
+void build_subtree(const pt_bvh_node& root, int threads, Builder& b) {
     if (threads <= 1 || root.count < kParallelMin) {
         b.threads = 1;
         b.run(root);
@@ -220,12 +300,12 @@ void build_subtree(const std::vector<PrimInfo>& prims, uint32_t* indices, const 
     b.max_depth = 1;
     if (!(root.count > 2 && b.partition(0))) return;
     const pt_bvh_node L = b.nodes[1], R = b.nodes[2];
-    Builder bl(prims, indices), br(prims, indices);
+    Builder bl(b.work, b.tmp, b.lpos), br(b.work, b.tmp, b.lpos);
     const uint64_t total = (uint64_t)L.count + R.count;
     int tl = (int)((uint64_t)threads * L.count / (total ? total : 1));
     tl = std::max(1, std::min(threads - 1, tl));
-    std::thread worker([&] { build_subtree(prims, indices, L, tl, bl); });
-    build_subtree(prims, indices, R, threads - tl, br);
+    std::thread worker([&] { build_subtree(L, tl, bl); });
+    build_subtree(R, threads - tl, br);
     worker.join();
     // splice: [root, L, R, nodes below L..., nodes below R...]; an internal node's link moves with its block
     const uint32_t nl = (uint32_t)bl.nodes.size() - 1, nr = (uint32_t)br.nodes.size() - 1;
@@ -252,16 +332,18 @@ void build_subtree(const std::vector<PrimInfo>& prims, uint32_t* indices, const 
 
 void prim_info_triangles(const float* pos, uint64_t n, std::vector<PrimInfo>& out) {
     out.resize(n);
-    for (uint64_t i = 0; i < n; ++i) {
-        const float* p = pos + 9 * i;
-        PrimInfo& pi = out[i];
-        for (int a = 0; a < 3; ++a) {
-            // Triangle::centre, triangle.rs:80-82; Triangle::bounds, triangle.rs:83-90
-            pi.c[a] = ((p[a] + p[3 + a]) + p[6 + a]) * (1.0f / 3.0f);
-            pi.mn[a] = mn2(mn2(p[a], p[3 + a]), p[6 + a]);
-            pi.mx[a] = mx2(mx2(p[a], p[3 + a]), p[6 + a]);
+    parallel_pieces(0, (uint32_t)n, default_threads(), [&](int, uint32_t a0, uint32_t b0) {
+        for (uint64_t i = a0; i < b0; ++i) {
+            const float* p = pos + 9 * i;
+            PrimInfo& pi = out[i];
+            for (int a = 0; a < 3; ++a) {
+                // Triangle::centre, triangle.rs:80-82; Triangle::bounds, triangle.rs:83-90
+                pi.c[a] = ((p[a] + p[3 + a]) + p[6 + a]) * (1.0f / 3.0f);
+                pi.mn[a] = mn2(mn2(p[a], p[3 + a]), p[6 + a]);
+                pi.mx[a] = mx2(mx2(p[a], p[3 + a]), p[6 + a]);
+            }
         }
-    }
+    });
 }
 
 void prim_info_spheres(const float* cr, uint64_t n, std::vector<PrimInfo>& out) {
@@ -279,21 +361,31 @@ void prim_info_spheres(const float* cr, uint64_t n, std::vector<PrimInfo>& out) 
 
 void build_bvh(const std::vector<PrimInfo>& prims, HostBVH& out, int threads) {
     const uint32_t n = (uint32_t)prims.size();
+    if (threads <= 0) threads = default_threads();
+    std::vector<Rec> work(n), tmp(threads > 1 && n >= kParallelNode ? n : 0);
+    std::vector<uint32_t> lpos(tmp.size());
+    std::vector<Box> roots((size_t)threads);
+    for (Box& b : roots) b.clear();
+    parallel_pieces(0, n, threads, [&](int t, uint32_t a, uint32_t b) {
+        Box r;
+        r.clear();
+        for (uint32_t i = a; i < b; ++i) {
+            const PrimInfo& p = prims[i];
+            Rec& w = work[i];
+            for (int k = 0; k < 3; ++k) { w.c[k] = p.c[k]; w.mn[k] = p.mn[k]; w.mx[k] = p.mx[k]; }
+            w.idx = i;
+            r.grow(p.mn, p.mx);
+        }
+        roots[(size_t)t] = r;
+    });
+    Box root = roots[0];
+    for (int t = 1; t < threads; ++t) root.grow(roots[(size_t)t].lo, roots[(size_t)t].hi);
+    Builder b(work.data(), tmp.data(), lpos.data());
+    build_subtree(pt_bvh_node{{root.lo[0], root.lo[1], root.lo[2]}, 0, {root.hi[0], root.hi[1], root.hi[2]}, n}, threads, b);
     out.indices.resize(n);
-    Box root;
-    root.clear();
-    for (uint32_t i = 0; i < n; ++i) {
-        out.indices[i] = i;
-        root.grow(prims[i].mn, prims[i].mx);
-    }
-    if (threads <= 0) {
-        const char* env = std::getenv("PTCORE_BUILD_THREADS");
-        threads = env ? std::atoi(env) : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
-        if (threads < 1) threads = 1;
-    }
-    Builder b(prims, out.indices.data());
-    build_subtree(prims, out.indices.data(), pt_bvh_node{{root.lo[0], root.lo[1], root.lo[2]}, 0, {root.hi[0], root.hi[1], root.hi[2]}, n},
-                  threads, b);
+    parallel_pieces(0, n, threads, [&](int, uint32_t a, uint32_t b0) {
+        for (uint32_t i = a; i < b0; ++i) out.indices[i] = work[i].idx;
+    });
     out.nodes = std::move(b.nodes);
     out.max_depth = b.max_depth;
     out.hazard = b.hazard;
