@@ -67,9 +67,11 @@ inline V3 cross(V3 a, V3 b) {
 }
 inline float magnitude(V3 a) { return std::sqrt(dot(a, a)); }
 inline V3 normalize(V3 a) { return a * (1.0f / magnitude(a)); }
-// Rust f32::min/max: return the non-NaN operand (== fminf/fmaxf)
-inline float fmin_(float a, float b) { return std::fmin(a, b); }
-inline float fmax_(float a, float b) { return std::fmax(a, b); }
+// Rust f32::min/max (llvm.minnum / maxnum as rustc's x86 backend lowers them): the non-NaN operand wins, and of two
+// equal operands (+0 / -0 included) the FIRST is returned.  Written out because libm disagrees on the tie: glibc's
+// fminf(-0, +0) is +0 (second operand), LLVM's lowering gives -0 (first); only the sign of a zero can differ.
+inline float fmin_(float a, float b) { return a != a ? b : (b < a ? b : a); }
+inline float fmax_(float a, float b) { return a != a ? b : (b > a ? b : a); }
 
 // ---------------------------------------------------------------- math mode
 enum { MATH_DET = 0, MATH_LIBM = 1 };

@@ -16,9 +16,10 @@ namespace {
 
 constexpr float kInfH = std::numeric_limits<float>::infinity();
 
-// f32::min / f32::max (non-NaN operand wins)
-inline float mn2(float a, float b) { return std::fmin(a, b); }
-inline float mx2(float a, float b) { return std::fmax(a, b); }
+// f32::min / f32::max: the non-NaN operand wins; of two equal operands (+0 / -0) the first is returned, as rustc's
+// lowering of llvm.minnum / maxnum does (written out: libm's fminf returns the second)
+inline float mn2(float a, float b) { return a != a ? b : (b < a ? b : a); }
+inline float mx2(float a, float b) { return a != a ? b : (b > a ? b : a); }
 
 struct Box {
     float lo[3], hi[3];
