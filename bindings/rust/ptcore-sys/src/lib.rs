@@ -126,6 +126,7 @@ extern "C" {
     pub fn pt_build(ctx: *mut pt_ctx) -> c_int;
     pub fn pt_set_bvh(ctx: *mut pt_ctx, nodes: *const pt_bvh_node, n_nodes: u64, indices: *const u64, n_indices: u64) -> c_int;
     pub fn pt_bvh_build(prim_kind: c_int, geom: *const f32, n: u64, nodes: *mut pt_bvh_node, nodes_cap: u64, indices: *mut u64, n_nodes_out: *mut u64, max_depth_out: *mut u32) -> c_int;
+    pub fn pt_get_build_info(ctx: *const pt_ctx, on_device: *mut u32, build_ms: *mut f64) -> c_int;
     pub fn pt_get_bvh_sizes(ctx: *const pt_ctx, n_nodes: *mut u64, n_indices: *mut u64, max_depth: *mut u32) -> c_int;
     pub fn pt_get_bvh(ctx: *const pt_ctx, nodes: *mut pt_bvh_node, indices: *mut u64) -> c_int;
     pub fn pt_set_camera(ctx: *mut pt_ctx, origin: *const f32, target: *const f32, width: u32, height: u32, lens_size: f32) -> c_int;

@@ -138,9 +138,15 @@ int pt_set_materials(pt_ctx *ctx, const pt_material *m, uint32_t count);
  * range and reads black, as the reference's oversize Vec does (src/scene.rs:174). */
 int pt_set_sky(pt_ctx *ctx, const float *rgb, uint32_t w, uint32_t h);
 
-/* BVH::new (src/bvh.rs:25-179): CPU binned-SAH build, bit-identical tree and leaf order,
- * then flattening + upload.  Also collects the lights list (src/bvh.rs:29-35). */
+/* BVH::new (src/bvh.rs:25-179): binned-SAH build, bit-identical tree and leaf order, then flattening + upload.
+ * Also collects the lights list (src/bvh.rs:29-35).  The tree is built on the GPU, one level at a time (SURVEY 8f row
+ * N3; PT_OPT_DEVICE_BUILD, default 1), or by the threaded host build when the option is 0 or when a primitive's
+ * centre or bounds hold a negative zero, an infinity or a NaN (a min / max over such values depends on the operand
+ * order, which only the host build reproduces).  Same tree either way. */
 int pt_build(pt_ctx *ctx);
+/* what the last pt_build did: *on_device = 1 when the tree was built on the GPU; *build_ms = the tree build alone
+ * (host or device, without flattening and upload).  No counterpart in the reference. */
+int pt_get_build_info(const pt_ctx *ctx, uint32_t *on_device, double *build_ms);
 /* Adopt a tree the host built itself — the north-star arrangement, where the Rust host keeps
  * BVH::new (src/bvh.rs:25-179) and hands over bvh_nodes + indices (src/bvh.rs:17-22).  The tree
  * is validated (ranges, coverage, no sharing), flattened and uploaded; use instead of pt_build. */
@@ -251,12 +257,13 @@ int pt_sample_skybox(pt_ctx *ctx, const float *dirs, uint64_t n, float *rgb);
  *  PT_OPT_TAIL_MODE       0 = fused phase-scheduled tail kernel, 1 = further rounds on the tail stream with a small
  *                         grid, 2 = fused tail kernel that traces and shades in lock step
  *  PT_OPT_SIMPLE_EXTEND   1 = one-ray-per-lane traversal kernel instead of the persistent one (A/B, tests)
+ *  PT_OPT_DEVICE_BUILD    1 = pt_build builds the tree on the GPU when the input allows it (default), 0 = always on the host
  *  PT_OPT_MERGE_QUEUED_CALLS  a pt_render_async call that continues the newest queued call (same frame, depth, seed,
  *                         shard and flags, the next sample indices) while that call has not started yet is added to it, up
  *                         to this many paths per merged call (default 128 Mi; 0 = never merge).  Same results, fewer and
  *                         larger launches when calls arrive faster than they are rendered */
 enum { PT_OPT_BATCH_PATHS = 0, PT_OPT_LANES = 1, PT_OPT_TAIL_MIN_PATHS = 2, PT_OPT_TAIL_FRACTION = 3,
-       PT_OPT_TAIL_STREAMS = 4, PT_OPT_TAIL_PATHS_PER_LANE = 5, PT_OPT_SIMPLE_EXTEND = 6, PT_OPT_BULK_STREAMS = 7, PT_OPT_TAIL_MODE = 8, PT_OPT_FIRST_CHECK_ROUND = 9, PT_OPT_RENDER_MODE = 10, PT_OPT_MERGE_QUEUED_CALLS = 11 };
+       PT_OPT_TAIL_STREAMS = 4, PT_OPT_TAIL_PATHS_PER_LANE = 5, PT_OPT_SIMPLE_EXTEND = 6, PT_OPT_BULK_STREAMS = 7, PT_OPT_TAIL_MODE = 8, PT_OPT_FIRST_CHECK_ROUND = 9, PT_OPT_RENDER_MODE = 10, PT_OPT_MERGE_QUEUED_CALLS = 11, PT_OPT_DEVICE_BUILD = 12 };
 int pt_set_option(pt_ctx *ctx, int option, uint64_t value);
 int pt_get_counters(pt_ctx *ctx, pt_counters *out);
 /* Diagnostics of the wavefront loop (no counterpart in the reference): after a pt_render with

@@ -16,6 +16,7 @@
 
 #include "../../include/ptcore.h"
 #include "pt_bvh.h"
+#include "pt_build.h"
 #include "pt_device.h"
 #include "pt_kernels.h"
 
@@ -31,6 +32,10 @@ struct DevBuf {
         p = nullptr;
         bytes = 0;
     }
+};
+
+struct ScopedBuf : DevBuf {  // a device buffer that lives for one call
+    ~ScopedBuf() { release(); }
 };
 
 constexpr uint32_t kMaxMaterials = 1u << 15;   // material id must fit the 15 bits saved across a look-ahead
@@ -166,6 +171,9 @@ struct pt_ctx {
     double render_ms = 0;
     uint64_t extend_launches = 0, tail_launches = 0;
     uint64_t opt_batch_slots = 0 /* 0 = the mode's default */, opt_tail_min = kTailMinPaths, opt_tail_fraction = kTailFraction, opt_lanes = 0 /* 0 = the mode's default */, opt_tail_streams = 4, opt_tail_paths_per_lane = 4, opt_first_check = 3, opt_simple_extend = 0, opt_bulk_streams = kMaxLanes, opt_tail_mode = 0, opt_render_mode = 1, opt_merge_calls = kMergeSlots;
+    uint64_t opt_device_build = 1;  // pt_build builds the tree on the GPU (pt_build.hip) when the input allows it
+    bool build_on_device = false;   // what the last pt_build did
+    double build_ms = 0;            // ... and how long the tree build itself took (without flattening / upload)
     uint64_t merged_calls = 0;  // pt_render_async calls that were added to a queued call instead of becoming a launch of their own
     std::vector<uint32_t> round_sizes;  // queue length of every round of the last finished batch
 
@@ -367,12 +375,32 @@ int pt_build(pt_ctx* c) {
     if (int rc = drain(c)) return rc;
     if (c->mats.empty()) return c->fail(PT_ERR_STATE, "pt_build: no materials set");
     const uint64_t n = c->mat_id.size();
+    const bool dbg = std::getenv("PTCORE_DEBUG") != nullptr;
+    auto tick = [&](const char* what, std::chrono::steady_clock::time_point since) {
+        if (dbg) std::fprintf(stderr, "[ptcore] pt_build: %-24s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - since).count());
+    };
+    auto t_info = std::chrono::steady_clock::now();
     std::vector<PrimInfo> info;
     if (c->prim_kind == PRIM_TRIANGLE) prim_info_triangles(c->pos.data(), n, info);
     else prim_info_spheres(c->cr.data(), n, info);
-    build_bvh(info, c->bvh);
+    tick("centres and bounds", t_info);
+    const auto t0 = std::chrono::steady_clock::now();
+    c->build_on_device = false;
+    if (c->opt_device_build) {  // same tree either way; inputs the device build cannot order (-0, inf, NaN) go to the host build
+        PT_HIP(c, hipSetDevice(c->device));
+        bool unsupported = false;
+        std::string why;
+        if (int rc = build_bvh_device(info, c->bvh, c->stream, &unsupported, &why)) return c->fail(rc, why);
+        c->build_on_device = !unsupported;
+    }
+    if (!c->build_on_device) build_bvh(info, c->bvh);
+    c->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    tick(c->build_on_device ? "tree (device)" : "tree (host)", t0);
     if (c->bvh.hazard) return c->fail(PT_ERR_BVH, "pt_build: a partition produced an empty child");
-    return finalize_scene(c);
+    const auto t_fin = std::chrono::steady_clock::now();
+    const int rc = finalize_scene(c);
+    tick("flatten, reorder, upload", t_fin);
+    return rc;
 }
 
 int pt_set_bvh(pt_ctx* c, const pt_bvh_node* nodes, uint64_t n_nodes, const uint64_t* indices, uint64_t n_indices) {
@@ -447,6 +475,13 @@ int pt_bvh_build(int prim_kind, const float* geom, uint64_t n, pt_bvh_node* node
 static int finalize_scene(pt_ctx* c) {
     PT_HIP(c, hipSetDevice(c->device));
     const uint64_t n = c->mat_id.size();
+    const bool dbg = std::getenv("PTCORE_DEBUG") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto tick = [&](const char* what) {
+        const auto now = std::chrono::steady_clock::now();
+        if (dbg) std::fprintf(stderr, "[ptcore] finalize: %-26s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     for (uint64_t i = 0; i < n; ++i)
         if (c->mat_id[i] >= c->mats.size()) return c->fail(PT_ERR_INVALID, "pt_build: material id out of range");
 
@@ -464,40 +499,40 @@ static int finalize_scene(pt_ctx* c) {
     // sphere leaves stay sequential (Sphere::intersect compares with ray.distance), so only the > 31 escape applies
     int rc = flatten_bvh(c->bvh, flat, (c->prim_kind == PRIM_TRIANGLE && kCoopLeafFrom != 0) ? kCoopLeafFrom : 32u);
     if (rc) return c->fail(rc, "pt_build: flatten failed");
+    tick("lights, flatten");
 
-    // primitives in leaf order
-    std::vector<uint32_t> slot_of(n);
-    for (uint64_t s = 0; s < n; ++s) slot_of[c->bvh.indices[s]] = (uint32_t)s;
-    if (c->prim_kind == PRIM_TRIANGLE) {
-        std::vector<float> rec(12 * n), nr(9 * n);
-        for (uint64_t s = 0; s < n; ++s) {
-            const uint32_t obj = c->bvh.indices[s];
-            const float* p = c->pos.data() + 9 * (size_t)obj;
-            float* r = rec.data() + 12 * s;
-            r[0] = p[0]; r[1] = p[1]; r[2] = p[2];
-            r[3] = p[3] - p[0]; r[4] = p[4] - p[1]; r[5] = p[5] - p[2];  // edge1 = position1 - position0
-            r[6] = p[6] - p[0]; r[7] = p[7] - p[1]; r[8] = p[8] - p[2];  // edge2 = position2 - position0
-            uint32_t id = obj, mat = c->mat_id[obj], zero = 0;
-            std::memcpy(r + 9, &id, 4);
-            std::memcpy(r + 10, &mat, 4);
-            std::memcpy(r + 11, &zero, 4);
-            std::memcpy(nr.data() + 9 * s, c->nrm.data() + 9 * (size_t)obj, 9 * sizeof(float));
+    // primitives in leaf order: the objects go up as they are and a kernel gathers them into their slots
+    // (a host loop over 10 M triangles took 0.6 s, most of it first-touch of the 840 MB it filled)
+    std::vector<uint32_t> slot_of;
+    {
+        ScopedBuf raw_a, raw_b, raw_mat, raw_idx, d_slot;
+        const uint32_t n32 = (uint32_t)n;
+        if ((rc = dev_upload(c, raw_mat, c->mat_id.data(), n * sizeof(uint32_t)))) return rc;
+        if ((rc = dev_upload(c, raw_idx, c->bvh.indices.data(), n * sizeof(uint32_t)))) return rc;
+        if ((rc = dev_alloc(c, d_slot, n * sizeof(uint32_t)))) return rc;
+        if (c->prim_kind == PRIM_TRIANGLE) {
+            if ((rc = dev_upload(c, raw_a, c->pos.data(), 9 * n * sizeof(float)))) return rc;
+            if ((rc = dev_upload(c, raw_b, c->nrm.data(), 9 * n * sizeof(float)))) return rc;
+            if ((rc = dev_alloc(c, c->d_prim, 12 * n * sizeof(float)))) return rc;
+            if ((rc = dev_alloc(c, c->d_nrm, 9 * n * sizeof(float)))) return rc;
+            if ((rc = dev_alloc(c, c->d_meta, 16))) return rc;
+            launch_reorder_triangles((const float*)raw_a.p, (const float*)raw_b.p, (const uint32_t*)raw_mat.p, (const uint32_t*)raw_idx.p, n32,
+                                     (float*)c->d_prim.p, (float*)c->d_nrm.p, (uint32_t*)d_slot.p, c->stream);
+        } else {
+            if ((rc = dev_upload(c, raw_a, c->cr.data(), 4 * n * sizeof(float)))) return rc;
+            if ((rc = dev_alloc(c, c->d_prim, 4 * n * sizeof(float)))) return rc;
+            if ((rc = dev_alloc(c, c->d_meta, 2 * n * sizeof(uint32_t)))) return rc;
+            if ((rc = dev_alloc(c, c->d_nrm, 16))) return rc;
+            launch_reorder_spheres((const float*)raw_a.p, (const uint32_t*)raw_mat.p, (const uint32_t*)raw_idx.p, n32, (float*)c->d_prim.p,
+                                   (uint32_t*)c->d_meta.p, (uint32_t*)d_slot.p, c->stream);
         }
-        if ((rc = dev_upload(c, c->d_prim, rec.data(), rec.size() * sizeof(float)))) return rc;
-        if ((rc = dev_upload(c, c->d_nrm, nr.data(), nr.size() * sizeof(float)))) return rc;
-        if ((rc = dev_alloc(c, c->d_meta, 16))) return rc;
-    } else {
-        std::vector<float> rec(4 * n);
-        std::vector<uint32_t> meta(2 * n);
-        for (uint64_t s = 0; s < n; ++s) {
-            const uint32_t obj = c->bvh.indices[s];
-            std::memcpy(rec.data() + 4 * s, c->cr.data() + 4 * (size_t)obj, 16);
-            meta[2 * s] = obj;
-            meta[2 * s + 1] = c->mat_id[obj];
+        PT_HIP(c, hipGetLastError());
+        PT_HIP(c, hipStreamSynchronize(c->stream));
+        if (!c->bvh.lights.empty()) {
+            slot_of.resize(n);
+            PT_HIP(c, hipMemcpy(slot_of.data(), d_slot.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
         }
-        if ((rc = dev_upload(c, c->d_prim, rec.data(), rec.size() * sizeof(float)))) return rc;
-        if ((rc = dev_upload(c, c->d_meta, meta.data(), meta.size() * sizeof(uint32_t)))) return rc;
-        if ((rc = dev_alloc(c, c->d_nrm, 16))) return rc;
+        tick("primitives to leaf order");
     }
     std::vector<uint32_t> light_slots;
     for (uint32_t obj : c->bvh.lights) light_slots.push_back(slot_of[obj]);
@@ -505,6 +540,7 @@ static int finalize_scene(pt_ctx* c) {
     if ((rc = dev_upload(c, c->d_big, flat.big_leaf.data(), flat.big_leaf.size() * sizeof(uint32_t)))) return rc;
     if ((rc = dev_upload(c, c->d_mats, c->mats.data(), c->mats.size() * sizeof(pt_material)))) return rc;
     if ((rc = dev_upload(c, c->d_lights, light_slots.data(), light_slots.size() * sizeof(uint32_t)))) return rc;
+    tick("upload tree");
 
     DevScene& S = c->ds;
     S.pairs = (const float4*)c->d_pairs.p;
@@ -529,6 +565,13 @@ static int finalize_scene(pt_ctx* c) {
     c->cfg.spill = (unsigned long long*)c->d_spill.p;
     c->built = true;
     c->have_cam = false;
+    return PT_OK;
+}
+
+int pt_get_build_info(const pt_ctx* c, uint32_t* on_device, double* build_ms) {
+    if (!c || !c->built) return PT_ERR_STATE;
+    if (on_device) *on_device = c->build_on_device ? 1u : 0u;
+    if (build_ms) *build_ms = c->build_ms;
     return PT_OK;
 }
 
@@ -1322,6 +1365,7 @@ int pt_set_option(pt_ctx* c, int option, uint64_t value) {
         case PT_OPT_RENDER_MODE: c->opt_render_mode = value; return PT_OK;
         case PT_OPT_TAIL_MODE: c->opt_tail_mode = value; return PT_OK;
         case PT_OPT_SIMPLE_EXTEND: c->opt_simple_extend = value; return PT_OK;
+        case PT_OPT_DEVICE_BUILD: c->opt_device_build = value != 0; return PT_OK;
         case PT_OPT_MERGE_QUEUED_CALLS: c->opt_merge_calls = std::min<uint64_t>(value, kMaxSlots - 1); return PT_OK;
         case PT_OPT_TAIL_PATHS_PER_LANE: c->opt_tail_paths_per_lane = std::max<uint64_t>(value, 1); return PT_OK;
         default: return c->fail(PT_ERR_INVALID, "pt_set_option: unknown option");

@@ -1,0 +1,632 @@
+// pt_build.hip — the reference's binned-SAH build (src/bvh.rs:25-179) on the GPU, same tree bit for bit.
+//
+// The reference builds depth first with an explicit stack; nothing in a node's split depends on any node outside its own
+// range of bvh.indices, so the tree can be built one LEVEL at a time, every node of a level at once, and numbered the
+// reference's way afterwards.  Per level (positions = places in bvh.indices, a node = a contiguous range of them):
+//   k_bin      every primitive of an active node: its three bin numbers (bvh.rs:125-133) -> bin bounds / counts
+//   k_sah      one thread per node: the sweep of bvh.rs:135-168 -> axis + pivot, or "no split beats the parent"
+//   k_flag     left / right flag per primitive (centre[axis] <= pivot, bvh.rs:70)
+//   scan       exclusive prefix sum of the flags over all positions -> rank of every left primitive in its node
+//   k_children two child nodes per split node, the next level's active list
+//   k_lpos / k_scatter  the reference's swap walk (bvh.rs:66-79) decides the order inside the two halves; its result
+//              is a function of the flags alone (pt_bvh.cpp, partition_large, has the argument): the k-th left object
+//              ends at place k, a right object at place p moves to l[p], l[l[p]] ... until its place is >= nL.  Child
+//              bounds (and the children's centre bounds for the next level) are reduced in the same pass.
+// Bounds are mins / maxes of input values (exact in any order), counts are integers, and the few float operations
+// (delta, bin number, areas, costs, pivot) are the same single IEEE operations in the same order as on the host
+// (-ffp-contract=off).  The one thing an unordered reduction cannot reproduce is which ZERO wins min(+0, -0), and NaN
+// bounds would need the reference's operand order too: inputs holding a negative zero or a non-finite value are
+// reported as unsupported and the caller builds on the host.
+// Numbering: the reference appends a node's two children when it splits the node, and splits in depth-first order, left
+// subtree first.  With s(v) = number of splits in v's subtree, the split of v's left child is event e(v) + 1 and the
+// right child's e(v) + 1 + s(left); children of the node split at event e are nodes 1 + 2e and 2 + 2e.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "pt_build.h"
+
+#pragma clang fp contract(off)
+
+namespace pt {
+namespace {
+
+constexpr uint32_t kNone = 0xffffffffu;
+constexpr uint32_t kKeyPosInf = 0xff800000u;  // key(+inf): identity of min
+constexpr uint32_t kKeyNegInf = 0x007fffffu;  // key(-inf): identity of max
+constexpr int kBlock = 256;
+
+// order-preserving map float -> uint32 (total order of finite values and infinities; -0 < +0, which is why inputs with
+// a negative zero are refused)
+__device__ __forceinline__ uint32_t f2key(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+struct Rec {  // pt_bvh.cpp's record: bvh.indices[i] with that object's centre and bounds
+    float c[3], mn[3], mx[3];
+    uint32_t idx;
+};
+
+struct BNode {  // 64 B, creation order (level by level)
+    uint32_t bmin[3], bmax[3];  // Primitive::bounds of the members, as keys
+    uint32_t cmin[3], cmax[3];  // bounds of their centres, as keys
+    uint32_t first, count;
+    uint32_t left;              // id of the left child (right = left + 1); 0 = leaf
+    uint32_t slot;              // place in the current level's active list, kNone when the node is finished
+};
+
+struct Bins {  // per active node
+    uint32_t mn[24][3], mx[24][3];
+    uint32_t n[24];
+};
+constexpr int kBinWords = sizeof(Bins) / 4;  // 168
+
+struct Split {
+    int axis;     // -1: no split beats the parent cost
+    float pivot;
+    uint32_t n_left, left_slot, right_slot, pair;  // filled by k_children
+};
+
+struct DBox {
+    float lo[3], hi[3];
+    __device__ void clear() {
+        for (int a = 0; a < 3; ++a) { lo[a] = __builtin_inff(); hi[a] = -__builtin_inff(); }
+    }
+    __device__ void grow(const DBox& o) {  // AABB::combine; no NaN and no negative zero ever gets here
+        for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], o.lo[a]); hi[a] = fmaxf(hi[a], o.hi[a]); }
+    }
+    __device__ float area() const {  // AABB::area, aabb.rs:42-45
+        const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+        return (2.0f * ex * ey + 2.0f * ex * ez) + 2.0f * ey * ez;
+    }
+};
+
+// ---- level 0: refuse what the keys cannot order, root bounds
+__global__ void k_root(const Rec* __restrict__ rec, uint32_t n, BNode* nodes, uint32_t* unsupported) {
+    __shared__ uint32_t acc[12];
+    if (threadIdx.x < 12) acc[threadIdx.x] = (threadIdx.x % 6) < 3 ? kKeyPosInf : kKeyNegInf;
+    __syncthreads();
+    bool bad = false;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const Rec r = rec[i];
+        for (int k = 0; k < 3; ++k)
+            for (const float f : {r.c[k], r.mn[k], r.mx[k]}) {
+                const uint32_t u = __float_as_uint(f);
+                bad = bad || u == 0x80000000u || (u & 0x7f800000u) == 0x7f800000u;
+            }
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&acc[a], f2key(r.mn[a]));
+            atomicMax(&acc[3 + a], f2key(r.mx[a]));
+            atomicMin(&acc[6 + a], f2key(r.c[a]));
+            atomicMax(&acc[9 + a], f2key(r.c[a]));
+        }
+    }
+    if (bad) atomicOr(unsupported, 1u);
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        uint32_t* dst = threadIdx.x < 3 ? &nodes[0].bmin[threadIdx.x] : threadIdx.x < 6 ? &nodes[0].bmax[threadIdx.x - 3]
+                        : threadIdx.x < 9 ? &nodes[0].cmin[threadIdx.x - 6] : &nodes[0].cmax[threadIdx.x - 9];
+        if ((threadIdx.x % 6) < 3) atomicMin(dst, acc[threadIdx.x]);
+        else atomicMax(dst, acc[threadIdx.x]);
+    }
+}
+
+__global__ void k_init_root(BNode* nodes, uint32_t n, uint32_t* seg, uint32_t* active) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        BNode r;
+        for (int a = 0; a < 3; ++a) { r.bmin[a] = r.cmin[a] = kKeyPosInf; r.bmax[a] = r.cmax[a] = kKeyNegInf; }
+        r.first = 0;
+        r.count = n;
+        r.left = 0;
+        r.slot = n > 2 ? 0 : kNone;
+        nodes[0] = r;
+        active[0] = 0;
+    }
+    if (i < n) seg[i] = n > 2 ? 0u : kNone;
+}
+
+__global__ void k_init_bins(Bins* bins, uint32_t n_active) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)n_active * kBinWords) return;
+    const uint32_t w = (uint32_t)(i % kBinWords);
+    ((uint32_t*)bins)[i] = w < 72 ? kKeyPosInf : (w < 144 ? kKeyNegInf : 0u);
+}
+
+// ---- binning.  A block whose positions all belong to one node reduces in LDS first.
+__global__ void k_bin(const Rec* __restrict__ rec, const uint32_t* __restrict__ seg, uint32_t n, const BNode* __restrict__ nodes,
+                      const uint32_t* __restrict__ active, Bins* bins) {
+    __shared__ uint32_t lb[kBinWords];
+    __shared__ uint32_t s0;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t s = i < n ? seg[i] : kNone;
+    if (threadIdx.x == 0) s0 = s;
+    __syncthreads();
+    const uint32_t first_s = s0;
+    const bool uniform = __syncthreads_and((i >= n || s == first_s) ? 1 : 0) != 0 && first_s != kNone;
+    if (uniform)
+        for (int w = threadIdx.x; w < kBinWords; w += blockDim.x) lb[w] = w < 72 ? kKeyPosInf : (w < 144 ? kKeyNegInf : 0u);
+    __syncthreads();
+    if (s != kNone) {
+        const BNode& nd = nodes[active[s]];
+        const Rec r = rec[i];
+        Bins* B = uniform ? (Bins*)lb : bins + s;
+        for (int a = 0; a < 3; ++a) {
+            const float lo = key2f(nd.cmin[a]), hi = key2f(nd.cmax[a]);
+            const float delta = (hi - lo) / 8.0f;                 // bvh.rs:121-123
+            const float q = (r.c[a] - lo) / delta;                // bvh.rs:127-132: NaN (0 / 0) -> bin 0
+            const int b = a * 8 + (int)fminf(fmaxf(q, 0.0f), 7.0f);
+            for (int k = 0; k < 3; ++k) {
+                atomicMin(&B->mn[b][k], f2key(r.mn[k]));
+                atomicMax(&B->mx[b][k], f2key(r.mx[k]));
+            }
+            atomicAdd(&B->n[b], 1u);
+        }
+    }
+    if (uniform) {
+        __syncthreads();
+        uint32_t* g = (uint32_t*)(bins + first_s);
+        for (int w = threadIdx.x; w < kBinWords; w += blockDim.x) {
+            const uint32_t v = lb[w];
+            if (w < 72) { if (v != kKeyPosInf) atomicMin(g + w, v); }
+            else if (w < 144) { if (v != kKeyNegInf) atomicMax(g + w, v); }
+            else if (v) atomicAdd(g + w, v);
+        }
+    }
+}
+
+// ---- bvh.rs:104-169 for one node per thread
+__global__ void k_sah(const uint32_t* __restrict__ active, uint32_t n_active, const BNode* __restrict__ nodes, const Bins* __restrict__ bins,
+                      Split* split) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_active) return;
+    const BNode& nd = nodes[active[s]];
+    DBox nb, cb;
+    for (int a = 0; a < 3; ++a) {
+        nb.lo[a] = key2f(nd.bmin[a]); nb.hi[a] = key2f(nd.bmax[a]);
+        cb.lo[a] = key2f(nd.cmin[a]); cb.hi[a] = key2f(nd.cmax[a]);
+    }
+    const float parent_cost = nb.area() * (float)nd.count;
+    const Bins& B = bins[s];
+    int best_axis = -1, best_bin = -1;
+    float best = parent_cost;
+    for (int a = 0; a < 3; ++a) {
+        DBox bb[8], right[8];
+        uint32_t bn[8], nright[8];
+        for (int k = 0; k < 8; ++k) {
+            for (int c = 0; c < 3; ++c) { bb[k].lo[c] = key2f(B.mn[a * 8 + k][c]); bb[k].hi[c] = key2f(B.mx[a * 8 + k][c]); }
+            bn[k] = B.n[a * 8 + k];
+        }
+        right[7] = bb[7];
+        nright[7] = bn[7];
+        for (int k = 6; k >= 0; --k) {
+            right[k] = right[k + 1];
+            right[k].grow(bb[k]);
+            nright[k] = nright[k + 1] + bn[k];
+        }
+        DBox left;
+        left.clear();
+        uint32_t nleft = 0;
+        for (int k = 0; k < 8; ++k) {
+            left.grow(bb[k]);
+            nleft += bn[k];
+            const float cost = (float)nleft * left.area() + (float)nright[k] * right[k].area();  // right includes bin k, bvh.rs:155
+            if (cost < best) { best_axis = a; best_bin = k; best = cost; }
+        }
+    }
+    Split sp{};
+    sp.axis = best_axis;
+    if (best_axis >= 0) {
+        const float delta = (cb.hi[best_axis] - cb.lo[best_axis]) / 8.0f;
+        sp.pivot = cb.lo[best_axis] + (float)(1 + best_bin) * delta;
+    }
+    sp.left_slot = sp.right_slot = kNone;
+    split[s] = sp;
+}
+
+__global__ void k_flag(const Rec* __restrict__ rec, const uint32_t* __restrict__ seg, uint32_t n, const Split* __restrict__ split, uint32_t* flags) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = seg[i];
+    uint32_t f = 0;
+    if (s != kNone) {
+        const Split sp = split[s];
+        if (sp.axis >= 0) f = rec[i].c[sp.axis] <= sp.pivot ? 1u : 0u;
+    }
+    flags[i] = f;
+}
+
+// ---- exclusive prefix sum of n flags into P[0..n] (P[n] = total): block sums, one block over the sums, apply
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kBlock * kScanItems;
+
+__device__ __forceinline__ uint32_t block_exclusive(uint32_t v, uint32_t* total) {  // 256 threads
+    __shared__ uint32_t wsum[kBlock / 64];
+    uint32_t inc = v;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t base = 0, all = 0;
+    for (int k = 0; k < kBlock / 64; ++k) {
+        if (k < w) base += wsum[k];
+        all += wsum[k];
+    }
+    __syncthreads();
+    *total = all;
+    return base + inc - v;
+}
+
+__global__ void k_scan_sums(const uint32_t* __restrict__ flags, uint32_t n, uint32_t* sums) {
+    const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    uint32_t v = 0;
+    for (int k = 0; k < kScanItems; ++k)
+        if (base + k < n) v += flags[base + k];
+    uint32_t total;
+    (void)block_exclusive(v, &total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+__global__ void k_scan_top(uint32_t* sums, uint32_t nb, uint32_t* P, uint32_t n) {  // one block
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < nb; b0 += kBlock) {
+        const uint32_t i = b0 + threadIdx.x;
+        const uint32_t v = i < nb ? sums[i] : 0;
+        uint32_t total;
+        const uint32_t ex = block_exclusive(v, &total);
+        const uint32_t c = carry;
+        if (i < nb) sums[i] = c + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) P[n] = carry;
+}
+
+__global__ void k_scan_apply(const uint32_t* __restrict__ flags, uint32_t n, const uint32_t* __restrict__ sums, uint32_t* P) {
+    const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    uint32_t f[kScanItems], v = 0;
+    for (int k = 0; k < kScanItems; ++k) {
+        f[k] = base + k < n ? flags[base + k] : 0;
+        v += f[k];
+    }
+    uint32_t total;
+    uint32_t run = sums[blockIdx.x] + block_exclusive(v, &total);
+    for (int k = 0; k < kScanItems; ++k) {
+        if (base + k < n) P[base + k] = run;
+        run += f[k];
+    }
+}
+
+// ---- children of the nodes that split; the next level's active list
+__global__ void k_children(const uint32_t* __restrict__ active, uint32_t n_active, BNode* nodes, Split* split, const uint32_t* __restrict__ P,
+                           uint32_t* counters /* [0] nodes, [1] next active, [2] hazard */, uint32_t* next_active) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_active) return;
+    const uint32_t v = active[s];
+    Split sp = split[s];
+    if (sp.axis < 0) {
+        nodes[v].slot = kNone;
+        return;
+    }
+    const uint32_t first = nodes[v].first, count = nodes[v].count;
+    const uint32_t nl = P[first + count] - P[first];
+    if (nl == 0 || nl == count) atomicOr(&counters[2], 1u);
+    const uint32_t pair = atomicAdd(&counters[0], 2u);
+    BNode c;
+    for (int a = 0; a < 3; ++a) { c.bmin[a] = c.cmin[a] = kKeyPosInf; c.bmax[a] = c.cmax[a] = kKeyNegInf; }
+    c.left = 0;
+    c.first = first;
+    c.count = nl;
+    c.slot = nl > 2 ? atomicAdd(&counters[1], 1u) : kNone;
+    if (c.slot != kNone) next_active[c.slot] = pair;
+    nodes[pair] = c;
+    sp.left_slot = c.slot;
+    c.first = first + nl;
+    c.count = count - nl;
+    c.slot = c.count > 2 ? atomicAdd(&counters[1], 1u) : kNone;
+    if (c.slot != kNone) next_active[c.slot] = pair + 1;
+    nodes[pair + 1] = c;
+    sp.right_slot = c.slot;
+    sp.n_left = nl;
+    sp.pair = pair;
+    split[s] = sp;
+    nodes[v].left = pair;
+    nodes[v].slot = kNone;
+}
+
+__global__ void k_lpos(const uint32_t* __restrict__ seg, uint32_t n, const uint32_t* __restrict__ flags, const uint32_t* __restrict__ P,
+                       const uint32_t* __restrict__ active, const BNode* __restrict__ nodes, uint32_t* lpos) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flags[i]) return;
+    const uint32_t first = nodes[active[seg[i]]].first;  // a set flag implies an active, split node
+    lpos[first + (P[i] - P[first])] = i - first;
+}
+
+// one pass: every active primitive to its place in the next level, child bounds reduced on the way
+__global__ void k_scatter(const Rec* __restrict__ rec, const uint32_t* __restrict__ seg, uint32_t n, const uint32_t* __restrict__ flags,
+                          const uint32_t* __restrict__ P, const uint32_t* __restrict__ lpos, const uint32_t* __restrict__ active, BNode* nodes,
+                          const Split* __restrict__ split, Rec* rec_next, uint32_t* seg_next, uint32_t* final_idx) {
+    __shared__ uint32_t acc[24];  // [child][bmin3 bmax3 cmin3 cmax3]
+    __shared__ uint32_t s0, pair_sh;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t s = i < n ? seg[i] : kNone;
+    if (threadIdx.x == 0) s0 = s;
+    __syncthreads();
+    const uint32_t first_s = s0;
+    const bool uniform = __syncthreads_and((i >= n || s == first_s) ? 1 : 0) != 0 && first_s != kNone;
+    if (uniform && threadIdx.x < 24) acc[threadIdx.x] = (threadIdx.x % 6) < 3 ? kKeyPosInf : kKeyNegInf;
+    __syncthreads();
+    uint32_t pair = 0;
+    bool did_split = false;
+    if (i < n) {
+        if (s == kNone) {
+            seg_next[i] = kNone;
+        } else {
+            const Split sp = split[s];
+            const Rec r = rec[i];
+            if (sp.axis < 0) {  // the node stays a leaf: its primitives are where they will be
+                final_idx[i] = r.idx;
+                seg_next[i] = kNone;
+            } else {
+                did_split = true;
+                pair = sp.pair;
+                const uint32_t first = nodes[active[s]].first;
+                uint32_t q;
+                if (flags[i]) {
+                    q = P[i] - P[first];
+                } else {
+                    q = i - first;
+                    while (q < sp.n_left) q = lpos[first + q];
+                }
+                const uint32_t right = q >= sp.n_left ? 1u : 0u;
+                const uint32_t cs = right ? sp.right_slot : sp.left_slot;
+                const uint32_t dest = first + q;
+                if (cs == kNone) final_idx[dest] = r.idx;  // a child of one or two primitives is never split
+                else rec_next[dest] = r;
+                seg_next[dest] = cs;
+                uint32_t* b = uniform ? acc + 12 * right : nodes[pair + right].bmin;  // bmin, bmax, cmin, cmax are consecutive
+                for (int a = 0; a < 3; ++a) {
+                    atomicMin(b + a, f2key(r.mn[a]));
+                    atomicMax(b + 3 + a, f2key(r.mx[a]));
+                    atomicMin(b + 6 + a, f2key(r.c[a]));
+                    atomicMax(b + 9 + a, f2key(r.c[a]));
+                }
+            }
+        }
+    }
+    if (uniform) {
+        if (threadIdx.x == 0) pair_sh = 0;
+        __syncthreads();
+        if (did_split) pair_sh = pair;  // same value from every thread of a uniform block
+        __syncthreads();
+        if (threadIdx.x < 24 && pair_sh) {
+            const uint32_t v = acc[threadIdx.x];
+            uint32_t* dst = nodes[pair_sh + threadIdx.x / 12].bmin + threadIdx.x % 12;
+            if ((threadIdx.x % 6) < 3) { if (v != kKeyPosInf) atomicMin(dst, v); }
+            else if (v != kKeyNegInf) atomicMax(dst, v);
+        }
+    }
+}
+
+// ---- numbering (see the header comment): splits per subtree bottom-up, split events and ids top-down, then the output
+__global__ void k_count_splits(const BNode* __restrict__ nodes, uint32_t lo, uint32_t hi, uint32_t* splits) {
+    const uint32_t v = lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= hi) return;
+    const uint32_t l = nodes[v].left;
+    splits[v] = l ? 1u + splits[l] + splits[l + 1] : 0u;
+}
+
+__global__ void k_number(const BNode* __restrict__ nodes, uint32_t lo, uint32_t hi, const uint32_t* __restrict__ splits, uint32_t* event, uint32_t* newid) {
+    const uint32_t v = lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= hi) return;
+    const uint32_t l = nodes[v].left;
+    if (!l) return;
+    const uint32_t e = event[v];
+    event[l] = e + 1;
+    event[l + 1] = e + 1 + splits[l];
+    newid[l] = 1 + 2 * e;
+    newid[l + 1] = 2 + 2 * e;
+}
+
+__global__ void k_emit(const BNode* __restrict__ nodes, uint32_t n_nodes, const uint32_t* __restrict__ newid, pt_bvh_node* out) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_nodes) return;
+    const BNode nd = nodes[v];
+    pt_bvh_node o;
+    for (int a = 0; a < 3; ++a) { o.min[a] = key2f(nd.bmin[a]); o.max[a] = key2f(nd.bmax[a]); }
+    o.left_first = nd.left ? newid[nd.left] : nd.first;
+    o.count = nd.left ? 0u : nd.count;
+    out[newid[v]] = o;
+}
+
+// ---- primitives into leaf order (what the traversal kernels read): slot s holds object indices[s]
+__global__ void k_reorder_tri(const float* __restrict__ pos, const float* __restrict__ nrm, const uint32_t* __restrict__ mat, const uint32_t* __restrict__ idx,
+                              uint32_t n, float* __restrict__ prim, float* __restrict__ nrm_out, uint32_t* __restrict__ slot_of) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const uint32_t obj = idx[s];
+    const float* p = pos + 9 * (size_t)obj;
+    float* r = prim + 12 * (size_t)s;
+    const float p0[3] = {p[0], p[1], p[2]};
+    for (int k = 0; k < 3; ++k) {
+        r[k] = p0[k];
+        r[3 + k] = p[3 + k] - p0[k];  // edge1 = position1 - position0
+        r[6 + k] = p[6 + k] - p0[k];  // edge2 = position2 - position0
+    }
+    r[9] = __uint_as_float(obj);
+    r[10] = __uint_as_float(mat[obj]);
+    r[11] = 0.0f;
+    for (int k = 0; k < 9; ++k) nrm_out[9 * (size_t)s + k] = nrm[9 * (size_t)obj + k];
+    slot_of[obj] = s;
+}
+
+__global__ void k_reorder_sph(const float* __restrict__ cr, const uint32_t* __restrict__ mat, const uint32_t* __restrict__ idx, uint32_t n,
+                              float* __restrict__ prim, uint32_t* __restrict__ meta, uint32_t* __restrict__ slot_of) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const uint32_t obj = idx[s];
+    for (int k = 0; k < 4; ++k) prim[4 * (size_t)s + k] = cr[4 * (size_t)obj + k];
+    meta[2 * (size_t)s] = obj;
+    meta[2 * (size_t)s + 1] = mat[obj];
+    slot_of[obj] = s;
+}
+
+struct Buf {
+    void* p = nullptr;
+    ~Buf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+inline uint32_t blocks(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
+
+}  // namespace
+
+#define BUILD_HIP(call)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            if (err) *err = std::string("device build: " #call ": ") + hipGetErrorString(e_);   \
+            return PT_ERR_HIP;                                                                  \
+        }                                                                                       \
+    } while (0)
+
+void launch_reorder_triangles(const float* pos, const float* nrm, const uint32_t* mat, const uint32_t* idx, uint32_t n, float* prim, float* nrm_out,
+                              uint32_t* slot_of, hipStream_t st) {
+    hipLaunchKernelGGL(k_reorder_tri, dim3(blocks(n)), dim3(kBlock), 0, st, pos, nrm, mat, idx, n, prim, nrm_out, slot_of);
+}
+
+void launch_reorder_spheres(const float* cr, const uint32_t* mat, const uint32_t* idx, uint32_t n, float* prim, uint32_t* meta, uint32_t* slot_of,
+                            hipStream_t st) {
+    hipLaunchKernelGGL(k_reorder_sph, dim3(blocks(n)), dim3(kBlock), 0, st, cr, mat, idx, n, prim, meta, slot_of);
+}
+
+int build_bvh_device(const std::vector<PrimInfo>& prims, HostBVH& out, hipStream_t st, bool* unsupported, std::string* err) {
+    const uint32_t n = (uint32_t)prims.size();
+    *unsupported = false;
+    if (n == 0 || prims.size() > kMaxPrims) return PT_ERR_INVALID;
+    static_assert(sizeof(Rec) == 40 && sizeof(BNode) == 64 && sizeof(Bins) == 672, "layout");
+
+    const bool dbg = std::getenv("PTCORE_DEBUG") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto tick = [&](const char* what) {
+        const auto now = std::chrono::steady_clock::now();
+        if (dbg) std::fprintf(stderr, "[ptcore] device build: %-22s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
+    // host records (index + centre + bounds), uploaded once
+    std::vector<Rec> host(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        std::memcpy(host[i].c, &prims[i], 36);
+        host[i].idx = i;
+    }
+    const uint32_t max_nodes = 2 * n + 1, max_active = n / 3 + 2, nb = (n + kScanTile - 1) / kScanTile;
+    Buf rec_a, rec_b, seg_a, seg_b, flags, P, lpos, sums, nodes, act_a, act_b, bins, split, counters, final_idx, splits, event, newid, outn;
+    BUILD_HIP(rec_a.alloc((size_t)n * sizeof(Rec)));
+    BUILD_HIP(rec_b.alloc((size_t)n * sizeof(Rec)));
+    BUILD_HIP(seg_a.alloc((size_t)n * 4));
+    BUILD_HIP(seg_b.alloc((size_t)n * 4));
+    BUILD_HIP(flags.alloc((size_t)n * 4));
+    BUILD_HIP(P.alloc(((size_t)n + 1) * 4));
+    BUILD_HIP(lpos.alloc((size_t)n * 4));
+    BUILD_HIP(sums.alloc((size_t)nb * 4));
+    BUILD_HIP(nodes.alloc((size_t)max_nodes * sizeof(BNode)));
+    BUILD_HIP(act_a.alloc((size_t)max_active * 4));
+    BUILD_HIP(act_b.alloc((size_t)max_active * 4));
+    BUILD_HIP(bins.alloc((size_t)max_active * sizeof(Bins)));
+    BUILD_HIP(split.alloc((size_t)max_active * sizeof(Split)));
+    BUILD_HIP(counters.alloc(16));
+    BUILD_HIP(final_idx.alloc((size_t)n * 4));
+    BUILD_HIP(hipMemcpyAsync(rec_a.p, host.data(), (size_t)n * sizeof(Rec), hipMemcpyHostToDevice, st));
+
+    uint32_t h_cnt[4] = {1, 0, 0, 0};  // nodes, next active, hazard, unsupported
+    BUILD_HIP(hipMemcpyAsync(counters.p, h_cnt, 16, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_init_root, dim3(blocks(n)), dim3(kBlock), 0, st, nodes.as<BNode>(), n, seg_a.as<uint32_t>(), act_a.as<uint32_t>());
+    hipLaunchKernelGGL(k_root, dim3(std::min<uint32_t>(blocks(n), 2048)), dim3(kBlock), 0, st, rec_a.as<Rec>(), n, nodes.as<BNode>(), counters.as<uint32_t>() + 3);
+    BUILD_HIP(hipMemcpyAsync(h_cnt, counters.p, 16, hipMemcpyDeviceToHost, st));
+    BUILD_HIP(hipStreamSynchronize(st));
+    BUILD_HIP(hipGetLastError());
+    if (h_cnt[3]) {
+        *unsupported = true;
+        return PT_OK;
+    }
+    tick("records, alloc, upload");
+    std::vector<uint32_t> level_start{0, 1};  // node ids of level L are [level_start[L], level_start[L + 1])
+    uint32_t n_active = n > 2 ? 1 : 0;
+    Buf *rc = &rec_a, *rn = &rec_b, *sc = &seg_a, *sn = &seg_b, *ac = &act_a, *an = &act_b;
+    if (n <= 2) {  // the root is the only node: its primitives stay in input order
+        std::vector<uint32_t> id(n);
+        for (uint32_t i = 0; i < n; ++i) id[i] = i;
+        BUILD_HIP(hipMemcpyAsync(final_idx.p, id.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+        BUILD_HIP(hipStreamSynchronize(st));
+    }
+    while (n_active) {
+        hipLaunchKernelGGL(k_init_bins, dim3(blocks((uint64_t)n_active * kBinWords)), dim3(kBlock), 0, st, bins.as<Bins>(), n_active);
+        hipLaunchKernelGGL(k_bin, dim3(blocks(n)), dim3(kBlock), 0, st, rc->as<Rec>(), sc->as<uint32_t>(), n, nodes.as<BNode>(), ac->as<uint32_t>(), bins.as<Bins>());
+        hipLaunchKernelGGL(k_sah, dim3(blocks(n_active)), dim3(kBlock), 0, st, ac->as<uint32_t>(), n_active, nodes.as<BNode>(), bins.as<Bins>(), split.as<Split>());
+        hipLaunchKernelGGL(k_flag, dim3(blocks(n)), dim3(kBlock), 0, st, rc->as<Rec>(), sc->as<uint32_t>(), n, split.as<Split>(), flags.as<uint32_t>());
+        hipLaunchKernelGGL(k_scan_sums, dim3(nb), dim3(kBlock), 0, st, flags.as<uint32_t>(), n, sums.as<uint32_t>());
+        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, st, sums.as<uint32_t>(), nb, P.as<uint32_t>(), n);
+        hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(kBlock), 0, st, flags.as<uint32_t>(), n, sums.as<uint32_t>(), P.as<uint32_t>());
+        BUILD_HIP(hipMemsetAsync(counters.as<uint32_t>() + 1, 0, 4, st));
+        hipLaunchKernelGGL(k_children, dim3(blocks(n_active)), dim3(kBlock), 0, st, ac->as<uint32_t>(), n_active, nodes.as<BNode>(), split.as<Split>(), P.as<uint32_t>(),
+                           counters.as<uint32_t>(), an->as<uint32_t>());
+        hipLaunchKernelGGL(k_lpos, dim3(blocks(n)), dim3(kBlock), 0, st, sc->as<uint32_t>(), n, flags.as<uint32_t>(), P.as<uint32_t>(), ac->as<uint32_t>(), nodes.as<BNode>(),
+                           lpos.as<uint32_t>());
+        hipLaunchKernelGGL(k_scatter, dim3(blocks(n)), dim3(kBlock), 0, st, rc->as<Rec>(), sc->as<uint32_t>(), n, flags.as<uint32_t>(), P.as<uint32_t>(), lpos.as<uint32_t>(),
+                           ac->as<uint32_t>(), nodes.as<BNode>(), split.as<Split>(), rn->as<Rec>(), sn->as<uint32_t>(), final_idx.as<uint32_t>());
+        BUILD_HIP(hipMemcpyAsync(h_cnt, counters.p, 12, hipMemcpyDeviceToHost, st));
+        BUILD_HIP(hipStreamSynchronize(st));
+        BUILD_HIP(hipGetLastError());
+        if (h_cnt[0] > level_start.back()) level_start.push_back(h_cnt[0]);
+        n_active = h_cnt[1];
+        std::swap(rc, rn);
+        std::swap(sc, sn);
+        std::swap(ac, an);
+        if (h_cnt[0] > max_nodes || n_active > max_active) {
+            if (err) *err = "device build: node count out of range";
+            return PT_ERR_BVH;
+        }
+    }
+    const uint32_t n_nodes = h_cnt[0], levels = (uint32_t)level_start.size() - 1;
+    tick("levels");
+
+    BUILD_HIP(splits.alloc((size_t)n_nodes * 4));
+    BUILD_HIP(event.alloc((size_t)n_nodes * 4));
+    BUILD_HIP(newid.alloc((size_t)n_nodes * 4));
+    BUILD_HIP(outn.alloc((size_t)n_nodes * sizeof(pt_bvh_node)));
+    BUILD_HIP(hipMemsetAsync(event.p, 0, 4, st));  // the root: split event 0, node 0
+    BUILD_HIP(hipMemsetAsync(newid.p, 0, 4, st));
+    for (uint32_t L = levels; L-- > 0;)
+        hipLaunchKernelGGL(k_count_splits, dim3(blocks(level_start[L + 1] - level_start[L])), dim3(kBlock), 0, st, nodes.as<BNode>(), level_start[L], level_start[L + 1],
+                           splits.as<uint32_t>());
+    for (uint32_t L = 0; L < levels; ++L)
+        hipLaunchKernelGGL(k_number, dim3(blocks(level_start[L + 1] - level_start[L])), dim3(kBlock), 0, st, nodes.as<BNode>(), level_start[L], level_start[L + 1],
+                           splits.as<uint32_t>(), event.as<uint32_t>(), newid.as<uint32_t>());
+    hipLaunchKernelGGL(k_emit, dim3(blocks(n_nodes)), dim3(kBlock), 0, st, nodes.as<BNode>(), n_nodes, newid.as<uint32_t>(), outn.as<pt_bvh_node>());
+    out.nodes.resize(n_nodes);
+    out.indices.resize(n);
+    BUILD_HIP(hipMemcpyAsync(out.nodes.data(), outn.p, (size_t)n_nodes * sizeof(pt_bvh_node), hipMemcpyDeviceToHost, st));
+    BUILD_HIP(hipMemcpyAsync(out.indices.data(), final_idx.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    BUILD_HIP(hipStreamSynchronize(st));
+    BUILD_HIP(hipGetLastError());
+    out.max_depth = levels;
+    out.hazard = h_cnt[2] != 0;
+    tick("numbering, download");
+    return PT_OK;
+}
+
+}  // namespace pt

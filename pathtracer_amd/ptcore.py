@@ -33,11 +33,11 @@ PT_OK = 0
 PT_ERR_INVALID, PT_ERR_STATE, PT_ERR_NO_DEVICE, PT_ERR_HIP, PT_ERR_LIMIT, PT_ERR_BVH = -1, -2, -3, -4, -5, -6
 SHARD_ALL, SHARD_TILES = 0, 1
 RENDER_TIMED, RENDER_COUNT = 1, 2
-OPT_BATCH_PATHS, OPT_LANES, OPT_TAIL_MIN_PATHS, OPT_TAIL_FRACTION, OPT_TAIL_STREAMS, OPT_TAIL_PATHS_PER_LANE, OPT_SIMPLE_EXTEND, OPT_BULK_STREAMS, OPT_TAIL_MODE, OPT_FIRST_CHECK_ROUND, OPT_RENDER_MODE, OPT_MERGE_QUEUED_CALLS = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
+OPT_BATCH_PATHS, OPT_LANES, OPT_TAIL_MIN_PATHS, OPT_TAIL_FRACTION, OPT_TAIL_STREAMS, OPT_TAIL_PATHS_PER_LANE, OPT_SIMPLE_EXTEND, OPT_BULK_STREAMS, OPT_TAIL_MODE, OPT_FIRST_CHECK_ROUND, OPT_RENDER_MODE, OPT_MERGE_QUEUED_CALLS, OPT_DEVICE_BUILD = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12
 
 EXPORTS = [
     "pt_strerror", "pt_last_error", "pt_create", "pt_destroy", "pt_set_triangles", "pt_set_spheres", "pt_set_materials",
-    "pt_set_sky", "pt_build", "pt_set_bvh", "pt_bvh_build", "pt_get_bvh_sizes", "pt_get_bvh", "pt_set_camera", "pt_get_camera", "pt_generate", "pt_render", "pt_render_async", "pt_wait",
+    "pt_set_sky", "pt_build", "pt_get_build_info", "pt_set_bvh", "pt_bvh_build", "pt_get_bvh_sizes", "pt_get_bvh", "pt_set_camera", "pt_get_camera", "pt_generate", "pt_render", "pt_render_async", "pt_wait",
     "pt_shard_map", "pt_shard_slab_floats", "pt_shard_pack", "pt_shard_unpack", "pt_reset_accum", "pt_read_accum", "pt_write_accum", "pt_read_rgb8", "pt_read_rgb8_latest", "pt_accum_device_ptr", "pt_add_external_samples", "pt_trace", "pt_trace_noalloc",
     "pt_sample_skybox", "pt_set_option", "pt_get_counters", "pt_get_round_stats", "pt_reset_counters",
 ]
@@ -224,6 +224,12 @@ class PathTracer:
         nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
         indices = np.ascontiguousarray(indices, dtype=np.uint64)
         self._ck(self.l.pt_set_bvh(self.h, _ptr(nodes), C.c_uint64(len(nodes)), _ptr(indices), C.c_uint64(len(indices))))
+
+    def build_info(self):
+        """(tree built on the GPU?, milliseconds of the tree build alone) of the last pt_build."""
+        on_dev, ms = C.c_uint32(), C.c_double()
+        self._ck(self.l.pt_get_build_info(self.h, C.byref(on_dev), C.byref(ms)))
+        return bool(on_dev.value), ms.value
 
     def bvh(self):
         n_nodes, n_idx, depth = C.c_uint64(), C.c_uint64(), C.c_uint32()

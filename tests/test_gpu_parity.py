@@ -66,6 +66,75 @@ def test_bvh_identical(pairs, name):
     assert gd == od
 
 
+def _bare_triangles(tri):
+    n = len(tri)
+    nrm = np.ascontiguousarray(np.tile(np.array([0, 1, 0], np.float32), (n, 3)))
+    return (np.ascontiguousarray(tri, np.float32), nrm, np.zeros(n, np.uint32), scenes.materials([scenes.diffuse(0.0, (0.5, 0.5, 0.5))]))
+
+
+def _device_build_cases():
+    rng = np.random.default_rng(17)
+    cases = {}
+    for n in (1, 2, 3, 4, 5, 7, 64, 257, 1000):
+        ctr = rng.uniform(-1, 1, size=(n, 1, 3))
+        cases["soup%d" % n] = _bare_triangles((ctr + rng.normal(scale=0.05, size=(n, 3, 3))).reshape(n, 9))
+    cases["soup70k"] = scenes.soup_scene(70000, 3)
+    cases["statue"] = scenes.statue_scene(120, 80, 64, 5)
+    # overlapping giants: deep tree; a stack of identical triangles: one large leaf (no split beats the parent)
+    n = 3000
+    ctr = rng.uniform(-1, 1, size=(n, 3))
+    a, b = rng.normal(size=(n, 3)), rng.normal(size=(n, 3))
+    tri = np.concatenate([ctr, ctr + a, ctr + b], axis=1).astype(np.float32)
+    tri[:300] = tri[0]
+    cases["overlap"] = _bare_triangles(tri)
+    cases["same_centre"] = _bare_triangles(np.tile(np.array([[0, 0, 0, 1, 0, 0, 0, 1, 0]], np.float32), (40, 1)) + np.float32(0.25))
+    # sorted along x: every split is as lopsided as the sweep allows
+    xs = np.sort(rng.uniform(0, 1, size=5000)).astype(np.float32) ** 8
+    tri = np.zeros((5000, 9), np.float32)
+    tri[:, 0::3] = xs[:, None] + np.array([0.0, 1e-4, 0.0], np.float32)
+    tri[:, 1::3] = np.array([0.1, 0.1, 0.2], np.float32)
+    tri[:, 2::3] = np.array([0.3, 0.3, 0.3], np.float32)
+    cases["sorted"] = _bare_triangles(tri)
+    cases["spheres_reference"] = scenes.default_scene()   # holds a literal -0.0 (scene.rs:128): goes to the host build
+    cr = np.concatenate([rng.uniform(-2, 2, size=(500, 3)), rng.uniform(0.01, 0.3, size=(500, 1))], axis=1).astype(np.float32)
+    cases["spheres500"] = (cr, np.zeros(500, np.uint32), scenes.default_scene()[2])
+    return cases
+
+
+def test_device_build_equals_host_build(ptcore, sky):
+    """pt_build on the GPU (pt_build.hip) against the threaded host build of the same library, which
+    the CPU suite pins to the oracle: node array, leaf order and depth bit for bit, from one primitive to 70 k, deep
+    and degenerate trees, spheres; the option switches it off; inputs it cannot order (negative zero, infinity) are
+    handed to the host build and still give the same tree."""
+    g = ptcore.PathTracer(0)
+    try:
+        for name, scene in _device_build_cases().items():
+            geom, kind = (scene[0], 1) if len(scene) == 3 else (scene[0], 0)
+            want_nodes, want_idx, want_depth = ptcore.bvh_build_host(geom, kind)
+            for on in (1, 0):
+                g.set_option(ptcore.OPT_DEVICE_BUILD, on)
+                g.set_scene(scene, sky)
+                nodes, idx, depth = g.bvh()
+                assert g.build_info()[0] == (bool(on) and name != "spheres_reference"), name
+                assert nodes.tobytes() == want_nodes.tobytes(), (name, on)
+                np.testing.assert_array_equal(idx, want_idx)
+                assert depth == want_depth, (name, on)
+        g.set_option(ptcore.OPT_DEVICE_BUILD, 1)
+        for bad in (np.float32(-0.0), np.float32(np.inf)):
+            scene = scenes.soup_scene(5000, 4)
+            pos = scene[0].copy()
+            pos[17, 1::3] = bad   # all three y of one triangle: its bounds and centre hold the value
+            scene = (pos,) + tuple(scene[1:])
+            g.set_scene(scene, sky)
+            assert g.build_info()[0] is False
+            want_nodes, want_idx, _ = ptcore.bvh_build_host(pos, 0)
+            nodes, idx, _ = g.bvh()
+            assert nodes.tobytes() == want_nodes.tobytes()
+            np.testing.assert_array_equal(idx, want_idx)
+    finally:
+        g.close()
+
+
 @pytest.mark.parametrize("name", list(SCENES))
 @pytest.mark.parametrize("any_hit", [False, True])
 def test_trace_bit_exact(pairs, name, any_hit):
