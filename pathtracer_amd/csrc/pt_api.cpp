@@ -171,6 +171,8 @@ struct pt_ctx {
     double render_ms = 0;
     uint64_t extend_launches = 0, tail_launches = 0;
     uint64_t opt_batch_slots = 0 /* 0 = the mode's default */, opt_tail_min = kTailMinPaths, opt_tail_fraction = kTailFraction, opt_lanes = 0 /* 0 = the mode's default */, opt_tail_streams = 4, opt_tail_paths_per_lane = 4, opt_first_check = 3, opt_simple_extend = 0, opt_bulk_streams = kMaxLanes, opt_tail_mode = 0, opt_render_mode = 1, opt_merge_calls = kMergeSlots;
+    DeviceTree dtree;               // the tree of a device build, kept on the GPU until pt_get_bvh asks for it
+    bool host_bvh_current = true;   // c->bvh.nodes / indices hold the tree (false: only dtree does)
     uint64_t opt_device_build = 1;  // pt_build builds the tree on the GPU (pt_build.hip) when the input allows it
     bool build_on_device = false;   // what the last pt_build did
     double build_ms = 0;            // ... and how long the tree build itself took (without flattening / upload)
@@ -294,6 +296,7 @@ void pt_destroy(pt_ctx* c) {
                       &c->d_accum, &c->d_rgb, &c->d_stage_in, &c->d_stage_out, &c->d_spill, &c->d_counters};
     for (DevBuf* b : bufs) b->release();
     if (c->h_rgb) (void)hipHostFree(c->h_rgb);
+    c->dtree.release();
     for (RenderLane& L : c->lanes) {
         DevBuf* lb[] = {&L.d_ro, &L.d_rd, &L.d_hit, &L.d_tp, &L.d_out, &L.d_acc, &L.d_pxs, &L.d_q0, &L.d_q1, &L.d_qn, &L.d_spill};
         for (DevBuf* b : lb) b->release();
@@ -367,7 +370,28 @@ int pt_set_sky(pt_ctx* c, const float* rgb, uint32_t w, uint32_t h) {
     return PT_OK;
 }
 
-static int finalize_scene(pt_ctx* c);
+// the objects as the caller gave them, in device memory for the length of one pt_build / pt_set_bvh
+struct RawGeom {
+    ScopedBuf a, b, mat;  // triangles: positions, normals; spheres: centre + radius, unused; material ids
+    bool uploaded = false;
+};
+
+static int upload_geometry(pt_ctx* c, RawGeom& g) {
+    if (g.uploaded) return PT_OK;
+    const uint64_t n = c->mat_id.size();
+    int rc;
+    if ((rc = dev_upload(c, g.mat, c->mat_id.data(), n * sizeof(uint32_t)))) return rc;
+    if (c->prim_kind == PRIM_TRIANGLE) {
+        if ((rc = dev_upload(c, g.a, c->pos.data(), 9 * n * sizeof(float)))) return rc;
+        if ((rc = dev_upload(c, g.b, c->nrm.data(), 9 * n * sizeof(float)))) return rc;
+    } else {
+        if ((rc = dev_upload(c, g.a, c->cr.data(), 4 * n * sizeof(float)))) return rc;
+    }
+    g.uploaded = true;
+    return PT_OK;
+}
+
+static int finalize_scene(pt_ctx* c, RawGeom& raw);
 
 int pt_build(pt_ctx* c) {
     if (!c) return PT_ERR_INVALID;
@@ -379,26 +403,44 @@ int pt_build(pt_ctx* c) {
     auto tick = [&](const char* what, std::chrono::steady_clock::time_point since) {
         if (dbg) std::fprintf(stderr, "[ptcore] pt_build: %-24s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - since).count());
     };
-    auto t_info = std::chrono::steady_clock::now();
-    std::vector<PrimInfo> info;
-    if (c->prim_kind == PRIM_TRIANGLE) prim_info_triangles(c->pos.data(), n, info);
-    else prim_info_spheres(c->cr.data(), n, info);
-    tick("centres and bounds", t_info);
-    const auto t0 = std::chrono::steady_clock::now();
+    PT_HIP(c, hipSetDevice(c->device));
+    RawGeom raw;
+    c->dtree.release();
     c->build_on_device = false;
+    c->built = false;
     if (c->opt_device_build) {  // same tree either way; inputs the device build cannot order (-0, inf, NaN) go to the host build
-        PT_HIP(c, hipSetDevice(c->device));
+        const auto t_up = std::chrono::steady_clock::now();
+        if (int rc = upload_geometry(c, raw)) return rc;
+        tick("upload objects", t_up);
+        const auto t0 = std::chrono::steady_clock::now();
         bool unsupported = false;
         std::string why;
-        if (int rc = build_bvh_device(info, c->bvh, c->stream, &unsupported, &why)) return c->fail(rc, why);
+        if (int rc = build_bvh_device(c->prim_kind == PRIM_TRIANGLE ? 0 : 1, (const float*)raw.a.p, (uint32_t)n, c->dtree, c->stream, &unsupported, &why))
+            return c->fail(rc, why);
         c->build_on_device = !unsupported;
+        if (c->build_on_device) {
+            c->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            tick("tree (device)", t0);
+            c->host_bvh_current = false;
+            c->bvh.nodes.clear();
+            c->bvh.indices.clear();
+            c->bvh.max_depth = c->dtree.max_depth;
+            c->bvh.hazard = c->dtree.hazard;
+        }
     }
-    if (!c->build_on_device) build_bvh(info, c->bvh);
-    c->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    tick(c->build_on_device ? "tree (device)" : "tree (host)", t0);
+    if (!c->build_on_device) {
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<PrimInfo> info;
+        if (c->prim_kind == PRIM_TRIANGLE) prim_info_triangles(c->pos.data(), n, info);
+        else prim_info_spheres(c->cr.data(), n, info);
+        build_bvh(info, c->bvh);
+        c->host_bvh_current = true;
+        c->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        tick("tree (host)", t0);
+    }
     if (c->bvh.hazard) return c->fail(PT_ERR_BVH, "pt_build: a partition produced an empty child");
     const auto t_fin = std::chrono::steady_clock::now();
-    const int rc = finalize_scene(c);
+    const int rc = finalize_scene(c, raw);
     tick("flatten, reorder, upload", t_fin);
     return rc;
 }
@@ -449,7 +491,12 @@ int pt_set_bvh(pt_ctx* c, const pt_bvh_node* nodes, uint64_t n_nodes, const uint
     for (uint64_t i = 0; i < n; ++i) c->bvh.indices[i] = (uint32_t)indices[i];
     c->bvh.max_depth = max_depth;
     c->bvh.hazard = false;
-    return finalize_scene(c);
+    c->dtree.release();
+    c->host_bvh_current = true;
+    c->build_on_device = false;
+    c->build_ms = 0;
+    RawGeom raw;
+    return finalize_scene(c, raw);
 }
 
 int pt_bvh_build(int prim_kind, const float* geom, uint64_t n, pt_bvh_node* nodes, uint64_t nodes_cap, uint64_t* indices,
@@ -472,7 +519,7 @@ int pt_bvh_build(int prim_kind, const float* geom, uint64_t n, pt_bvh_node* node
     return PT_OK;
 }
 
-static int finalize_scene(pt_ctx* c) {
+static int finalize_scene(pt_ctx* c, RawGeom& raw) {
     PT_HIP(c, hipSetDevice(c->device));
     const uint64_t n = c->mat_id.size();
     const bool dbg = std::getenv("PTCORE_DEBUG") != nullptr;
@@ -494,37 +541,61 @@ static int finalize_scene(pt_ctx* c) {
         if (m.kind == PT_MAT_DIFFUSE && std::fmin(1.0f - m.a, 0.0f) != 0.0f) neg_nee = true;
     c->nee = neg_nee && !c->bvh.lights.empty();
 
-    FlatBVH flat;
     // triangle leaves of kCoopLeafFrom primitives or more are marked for wave-cooperative testing (step_prim_wave);
     // sphere leaves stay sequential (Sphere::intersect compares with ray.distance), so only the > 31 escape applies
-    int rc = flatten_bvh(c->bvh, flat, (c->prim_kind == PRIM_TRIANGLE && kCoopLeafFrom != 0) ? kCoopLeafFrom : 32u);
-    if (rc) return c->fail(rc, "pt_build: flatten failed");
+    const uint32_t big_from = (c->prim_kind == PRIM_TRIANGLE && kCoopLeafFrom != 0) ? kCoopLeafFrom : 32u;
+    const bool on_device = !c->host_bvh_current;  // the tree is in c->dtree only
+    int rc;
+    uint32_t root_ref = 0;
+    float root_min[3], root_max[3];
+    if (on_device) {
+        DeviceFlat flat;
+        std::string why;
+        if ((rc = flatten_bvh_device(c->dtree, big_from, flat, c->stream, &why))) return c->fail(rc, why);
+        c->d_pairs.release();
+        c->d_big.release();
+        c->d_pairs.p = flat.pairs;
+        c->d_pairs.bytes = flat.pairs_bytes;
+        c->d_big.p = flat.big_leaf;
+        c->d_big.bytes = flat.big_bytes;
+        root_ref = flat.root_ref;
+        for (int a = 0; a < 3; ++a) { root_min[a] = flat.root_min[a]; root_max[a] = flat.root_max[a]; }
+    } else {
+        FlatBVH flat;
+        rc = flatten_bvh(c->bvh, flat, big_from);
+        if (rc) return c->fail(rc, "pt_build: flatten failed");
+        if ((rc = dev_upload(c, c->d_pairs, flat.pairs.data(), flat.pairs.size() * sizeof(PairRecord)))) return rc;
+        if ((rc = dev_upload(c, c->d_big, flat.big_leaf.data(), flat.big_leaf.size() * sizeof(uint32_t)))) return rc;
+        root_ref = flat.root_ref;
+        for (int a = 0; a < 3; ++a) { root_min[a] = flat.root_min[a]; root_max[a] = flat.root_max[a]; }
+    }
     tick("lights, flatten");
 
     // primitives in leaf order: the objects go up as they are and a kernel gathers them into their slots
     // (a host loop over 10 M triangles took 0.6 s, most of it first-touch of the 840 MB it filled)
     std::vector<uint32_t> slot_of;
     {
-        ScopedBuf raw_a, raw_b, raw_mat, raw_idx, d_slot;
+        ScopedBuf raw_idx, d_slot;
         const uint32_t n32 = (uint32_t)n;
-        if ((rc = dev_upload(c, raw_mat, c->mat_id.data(), n * sizeof(uint32_t)))) return rc;
-        if ((rc = dev_upload(c, raw_idx, c->bvh.indices.data(), n * sizeof(uint32_t)))) return rc;
+        if ((rc = upload_geometry(c, raw))) return rc;
+        const uint32_t* d_idx = c->dtree.indices;
+        if (!on_device) {
+            if ((rc = dev_upload(c, raw_idx, c->bvh.indices.data(), n * sizeof(uint32_t)))) return rc;
+            d_idx = (const uint32_t*)raw_idx.p;
+        }
         if ((rc = dev_alloc(c, d_slot, n * sizeof(uint32_t)))) return rc;
         if (c->prim_kind == PRIM_TRIANGLE) {
-            if ((rc = dev_upload(c, raw_a, c->pos.data(), 9 * n * sizeof(float)))) return rc;
-            if ((rc = dev_upload(c, raw_b, c->nrm.data(), 9 * n * sizeof(float)))) return rc;
             if ((rc = dev_alloc(c, c->d_prim, 12 * n * sizeof(float)))) return rc;
             if ((rc = dev_alloc(c, c->d_nrm, 9 * n * sizeof(float)))) return rc;
             if ((rc = dev_alloc(c, c->d_meta, 16))) return rc;
-            launch_reorder_triangles((const float*)raw_a.p, (const float*)raw_b.p, (const uint32_t*)raw_mat.p, (const uint32_t*)raw_idx.p, n32,
-                                     (float*)c->d_prim.p, (float*)c->d_nrm.p, (uint32_t*)d_slot.p, c->stream);
+            launch_reorder_triangles((const float*)raw.a.p, (const float*)raw.b.p, (const uint32_t*)raw.mat.p, d_idx, n32, (float*)c->d_prim.p,
+                                     (float*)c->d_nrm.p, (uint32_t*)d_slot.p, c->stream);
         } else {
-            if ((rc = dev_upload(c, raw_a, c->cr.data(), 4 * n * sizeof(float)))) return rc;
             if ((rc = dev_alloc(c, c->d_prim, 4 * n * sizeof(float)))) return rc;
             if ((rc = dev_alloc(c, c->d_meta, 2 * n * sizeof(uint32_t)))) return rc;
             if ((rc = dev_alloc(c, c->d_nrm, 16))) return rc;
-            launch_reorder_spheres((const float*)raw_a.p, (const uint32_t*)raw_mat.p, (const uint32_t*)raw_idx.p, n32, (float*)c->d_prim.p,
-                                   (uint32_t*)c->d_meta.p, (uint32_t*)d_slot.p, c->stream);
+            launch_reorder_spheres((const float*)raw.a.p, (const uint32_t*)raw.mat.p, d_idx, n32, (float*)c->d_prim.p, (uint32_t*)c->d_meta.p,
+                                   (uint32_t*)d_slot.p, c->stream);
         }
         PT_HIP(c, hipGetLastError());
         PT_HIP(c, hipStreamSynchronize(c->stream));
@@ -536,8 +607,6 @@ static int finalize_scene(pt_ctx* c) {
     }
     std::vector<uint32_t> light_slots;
     for (uint32_t obj : c->bvh.lights) light_slots.push_back(slot_of[obj]);
-    if ((rc = dev_upload(c, c->d_pairs, flat.pairs.data(), flat.pairs.size() * sizeof(PairRecord)))) return rc;
-    if ((rc = dev_upload(c, c->d_big, flat.big_leaf.data(), flat.big_leaf.size() * sizeof(uint32_t)))) return rc;
     if ((rc = dev_upload(c, c->d_mats, c->mats.data(), c->mats.size() * sizeof(pt_material)))) return rc;
     if ((rc = dev_upload(c, c->d_lights, light_slots.data(), light_slots.size() * sizeof(uint32_t)))) return rc;
     tick("upload tree");
@@ -552,11 +621,11 @@ static int finalize_scene(pt_ctx* c) {
     S.lights = (const uint32_t*)c->d_lights.p;
     S.n_lights = (uint32_t)light_slots.size();
     S.n_prims = (uint32_t)n;
-    S.root_ref = flat.root_ref;
+    S.root_ref = root_ref;
     S.stack_cap = c->bvh.max_depth > 0 ? c->bvh.max_depth - 1 : 0;
     for (int a = 0; a < 3; ++a) {
-        S.root_min[a] = flat.root_min[a];
-        S.root_max[a] = flat.root_max[a];
+        S.root_min[a] = root_min[a];
+        S.root_max[a] = root_max[a];
     }
     // overflow area of the LDS stacks: exactly the levels the tree can need beyond kLdsStack
     const uint32_t extra = S.stack_cap > (uint32_t)kLdsStack ? S.stack_cap - kLdsStack : 0;
@@ -577,14 +646,22 @@ int pt_get_build_info(const pt_ctx* c, uint32_t* on_device, double* build_ms) {
 
 int pt_get_bvh_sizes(const pt_ctx* c, uint64_t* n_nodes, uint64_t* n_indices, uint32_t* max_depth) {
     if (!c || !c->built) return PT_ERR_STATE;
-    if (n_nodes) *n_nodes = c->bvh.nodes.size();
-    if (n_indices) *n_indices = c->bvh.indices.size();
+    if (n_nodes) *n_nodes = c->host_bvh_current ? c->bvh.nodes.size() : c->dtree.n_nodes;
+    if (n_indices) *n_indices = c->host_bvh_current ? c->bvh.indices.size() : c->dtree.n_prims;
     if (max_depth) *max_depth = c->bvh.max_depth;
     return PT_OK;
 }
 
-int pt_get_bvh(const pt_ctx* c, pt_bvh_node* nodes, uint64_t* indices) {
-    if (!c || !c->built) return PT_ERR_STATE;
+int pt_get_bvh(const pt_ctx* cc, pt_bvh_node* nodes, uint64_t* indices) {
+    if (!cc || !cc->built) return PT_ERR_STATE;
+    pt_ctx* c = const_cast<pt_ctx*>(cc);  // a device-built tree comes to the host the first time it is asked for
+    if (!c->host_bvh_current) {
+        PT_HIP(c, hipSetDevice(c->device));
+        std::string why;
+        if (int rc = download_tree(c->dtree, c->bvh, c->stream, &why)) return c->fail(rc, why);
+        c->host_bvh_current = true;
+        c->dtree.release();
+    }
     if (nodes) std::memcpy(nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * sizeof(pt_bvh_node));
     if (indices)
         for (size_t i = 0; i < c->bvh.indices.size(); ++i) indices[i] = c->bvh.indices[i];

@@ -10,10 +10,33 @@
 
 namespace pt {
 
-// Builds out.nodes / out.indices / out.max_depth / out.hazard on the current device (work enqueued on `st`, returns
-// after it has finished).  *unsupported = true (and nothing built) when an input value is a negative zero, infinite or
-// NaN: min / max of such values depend on operand order, which only the host build reproduces.
-int build_bvh_device(const std::vector<PrimInfo>& prims, HostBVH& out, hipStream_t st, bool* unsupported, std::string* err);
+// What a device build leaves on the GPU (owned by the holder; release() frees it).
+struct DeviceTree {
+    pt_bvh_node* nodes = nullptr;  // the reference's node array, the reference's numbering
+    uint32_t* indices = nullptr;   // bvh.indices after the build
+    uint32_t n_nodes = 0, n_prims = 0, max_depth = 0;
+    bool hazard = false;
+    void release();
+};
+
+// The flattened tree (pt_bvh.h FlatBVH) in device memory; pairs / big_leaf are hipMalloc'ed and handed to the caller.
+struct DeviceFlat {
+    void* pairs = nullptr;
+    void* big_leaf = nullptr;
+    size_t pairs_bytes = 0, big_bytes = 0;
+    uint32_t root_ref = 0;
+    float root_min[3], root_max[3];
+};
+
+// Builds the tree on the current device from geometry that is already there (prim_kind 0: n x 9 triangle positions,
+// 1: n x 4 spheres); work is enqueued on `st` and has finished on return.  *unsupported = true (and nothing built) when
+// an input value is a negative zero, infinite or NaN: min / max of such values depend on operand order, which only
+// the host build reproduces.
+int build_bvh_device(int prim_kind, const float* d_geom, uint32_t n, DeviceTree& out, hipStream_t st, bool* unsupported, std::string* err);
+// flatten_bvh() of pt_bvh.h on the device (pair records in node order; big-leaf slots in node order)
+int flatten_bvh_device(const DeviceTree& t, uint32_t big_from, DeviceFlat& out, hipStream_t st, std::string* err);
+// nodes + indices to the host (pt_get_bvh)
+int download_tree(const DeviceTree& t, HostBVH& out, hipStream_t st, std::string* err);
 
 // Primitives into leaf order, on the device (all pointers device memory): slot s gets object idx[s] — triangles as
 // {p0, p1 - p0, p2 - p0, object id, material, 0} plus their nine normal floats, spheres as {centre, radius} plus

@@ -88,6 +88,46 @@ struct DBox {
     }
 };
 
+// ---- Primitive::centre / bounds of every object (triangle.rs:80-90, sphere.rs:81-91), the same single operations as
+// prim_info_triangles / prim_info_spheres on the host
+__global__ void k_recs_tri(const float* __restrict__ pos, uint32_t n, Rec* rec) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* p = pos + 9 * (size_t)i;
+    Rec r;
+    for (int a = 0; a < 3; ++a) {
+        r.c[a] = ((p[a] + p[3 + a]) + p[6 + a]) * (1.0f / 3.0f);
+        r.mn[a] = fminf(fminf(p[a], p[3 + a]), p[6 + a]);   // ties between zeros of both signs and NaNs: such inputs are refused (k_root)
+        r.mx[a] = fmaxf(fmaxf(p[a], p[3 + a]), p[6 + a]);
+    }
+    r.idx = i;
+    rec[i] = r;
+}
+
+__global__ void k_recs_sph(const float* __restrict__ cr, uint32_t n, Rec* rec) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* s = cr + 4 * (size_t)i;
+    Rec r;
+    for (int a = 0; a < 3; ++a) {
+        r.c[a] = s[a];
+        r.mn[a] = s[a] - s[3];
+        r.mx[a] = s[a] + s[3];
+    }
+    r.idx = i;
+    rec[i] = r;
+}
+
+// a vertex coordinate that is a negative zero or not finite (the records only hold min / max / sums of them)
+__global__ void k_check_input(const float* __restrict__ v, uint64_t n, uint32_t* unsupported) {
+    bool bad = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t u = __float_as_uint(v[i]);
+        bad = bad || u == 0x80000000u || (u & 0x7f800000u) == 0x7f800000u;
+    }
+    if (bad) atomicOr(unsupported, 1u);
+}
+
 // ---- level 0: refuse what the keys cannot order, root bounds
 __global__ void k_root(const Rec* __restrict__ rec, uint32_t n, BNode* nodes, uint32_t* unsupported) {
     __shared__ uint32_t acc[12];
@@ -484,12 +524,59 @@ __global__ void k_reorder_sph(const float* __restrict__ cr, const uint32_t* __re
     slot_of[obj] = s;
 }
 
+// ---- flattening (pt_bvh.cpp flatten_bvh) on the device: one 64-byte record per internal node holding its two children
+__global__ void k_node_flags(const pt_bvh_node* __restrict__ nodes, uint32_t n_nodes, uint32_t big_from, uint32_t* internal, uint32_t* big) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const uint32_t cnt = nodes[i].count;
+    internal[i] = cnt == 0 ? 1u : 0u;
+    big[i] = (cnt != 0 && !(cnt < big_from && cnt <= 31)) ? 1u : 0u;
+}
+
+__device__ __forceinline__ uint32_t make_ref(const pt_bvh_node& nd, uint32_t id, const uint32_t* pair_of, const uint32_t* big_of, uint32_t big_from,
+                                             uint32_t* big_leaf) {
+    if (nd.count == 0) return pair_of[id];
+    if (nd.count < big_from && nd.count <= 31) return kLeafBit | (nd.count << kLeafCountShift) | nd.left_first;
+    const uint32_t slot = big_of[id];
+    big_leaf[2 * slot] = nd.left_first;
+    big_leaf[2 * slot + 1] = nd.count;
+    return kLeafBit | slot;
+}
+
+__global__ void k_flatten(const pt_bvh_node* __restrict__ nodes, uint32_t n_nodes, const uint32_t* __restrict__ pair_of, const uint32_t* __restrict__ big_of,
+                          uint32_t big_from, PairRecord* pairs, uint32_t* big_leaf, uint32_t* root_ref) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const pt_bvh_node nd = nodes[i];
+    if (i == 0) *root_ref = make_ref(nd, 0, pair_of, big_of, big_from, big_leaf);
+    if (nd.count != 0) return;
+    const pt_bvh_node l = nodes[nd.left_first], r = nodes[nd.left_first + 1];
+    PairRecord p;
+    for (int a = 0; a < 3; ++a) {
+        p.lmin[a] = l.min[a]; p.lmax[a] = l.max[a];
+        p.rmin[a] = r.min[a]; p.rmax[a] = r.max[a];
+    }
+    p.lref = make_ref(l, nd.left_first, pair_of, big_of, big_from, big_leaf);
+    p.rref = make_ref(r, nd.left_first + 1, pair_of, big_of, big_from, big_leaf);
+    p.lpad = p.rpad = 0;
+    pairs[pair_of[i]] = p;
+}
+
 struct Buf {
     void* p = nullptr;
     ~Buf() { if (p) (void)hipFree(p); }
     hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
     template <class T> T* as() const { return (T*)p; }
+    void* take() { void* q = p; p = nullptr; return q; }
 };
+
+// exclusive prefix sum of n flags into P[0..n]
+void scan_flags(const uint32_t* flags, uint32_t n, uint32_t* sums, uint32_t* P, hipStream_t st) {
+    const uint32_t nb = (n + kScanTile - 1) / kScanTile;
+    hipLaunchKernelGGL(k_scan_sums, dim3(nb), dim3(kBlock), 0, st, flags, n, sums);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, st, sums, nb, P, n);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(kBlock), 0, st, flags, n, (const uint32_t*)sums, P);
+}
 
 inline uint32_t blocks(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
 
@@ -514,10 +601,19 @@ void launch_reorder_spheres(const float* cr, const uint32_t* mat, const uint32_t
     hipLaunchKernelGGL(k_reorder_sph, dim3(blocks(n)), dim3(kBlock), 0, st, cr, mat, idx, n, prim, meta, slot_of);
 }
 
-int build_bvh_device(const std::vector<PrimInfo>& prims, HostBVH& out, hipStream_t st, bool* unsupported, std::string* err) {
-    const uint32_t n = (uint32_t)prims.size();
+void DeviceTree::release() {
+    if (nodes) (void)hipFree(nodes);
+    if (indices) (void)hipFree(indices);
+    nodes = nullptr;
+    indices = nullptr;
+    n_nodes = n_prims = max_depth = 0;
+    hazard = false;
+}
+
+int build_bvh_device(int prim_kind, const float* d_geom, uint32_t n, DeviceTree& out, hipStream_t st, bool* unsupported, std::string* err) {
     *unsupported = false;
-    if (n == 0 || prims.size() > kMaxPrims) return PT_ERR_INVALID;
+    out.release();
+    if (n == 0 || n > kMaxPrims || !d_geom) return PT_ERR_INVALID;
     static_assert(sizeof(Rec) == 40 && sizeof(BNode) == 64 && sizeof(Bins) == 672, "layout");
 
     const bool dbg = std::getenv("PTCORE_DEBUG") != nullptr;
@@ -527,12 +623,6 @@ int build_bvh_device(const std::vector<PrimInfo>& prims, HostBVH& out, hipStream
         if (dbg) std::fprintf(stderr, "[ptcore] device build: %-22s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
         t_last = now;
     };
-    // host records (index + centre + bounds), uploaded once
-    std::vector<Rec> host(n);
-    for (uint32_t i = 0; i < n; ++i) {
-        std::memcpy(host[i].c, &prims[i], 36);
-        host[i].idx = i;
-    }
     const uint32_t max_nodes = 2 * n + 1, max_active = n / 3 + 2, nb = (n + kScanTile - 1) / kScanTile;
     Buf rec_a, rec_b, seg_a, seg_b, flags, P, lpos, sums, nodes, act_a, act_b, bins, split, counters, final_idx, splits, event, newid, outn;
     BUILD_HIP(rec_a.alloc((size_t)n * sizeof(Rec)));
@@ -550,10 +640,13 @@ int build_bvh_device(const std::vector<PrimInfo>& prims, HostBVH& out, hipStream
     BUILD_HIP(split.alloc((size_t)max_active * sizeof(Split)));
     BUILD_HIP(counters.alloc(16));
     BUILD_HIP(final_idx.alloc((size_t)n * 4));
-    BUILD_HIP(hipMemcpyAsync(rec_a.p, host.data(), (size_t)n * sizeof(Rec), hipMemcpyHostToDevice, st));
-
     uint32_t h_cnt[4] = {1, 0, 0, 0};  // nodes, next active, hazard, unsupported
     BUILD_HIP(hipMemcpyAsync(counters.p, h_cnt, 16, hipMemcpyHostToDevice, st));
+    const uint64_t n_floats = (uint64_t)n * (prim_kind == 0 ? 9 : 4);
+    hipLaunchKernelGGL(k_check_input, dim3((uint32_t)std::min<uint64_t>((n_floats + kBlock - 1) / kBlock, 4096)), dim3(kBlock), 0, st, d_geom, n_floats,
+                       counters.as<uint32_t>() + 3);
+    if (prim_kind == 0) hipLaunchKernelGGL(k_recs_tri, dim3(blocks(n)), dim3(kBlock), 0, st, d_geom, n, rec_a.as<Rec>());
+    else hipLaunchKernelGGL(k_recs_sph, dim3(blocks(n)), dim3(kBlock), 0, st, d_geom, n, rec_a.as<Rec>());
     hipLaunchKernelGGL(k_init_root, dim3(blocks(n)), dim3(kBlock), 0, st, nodes.as<BNode>(), n, seg_a.as<uint32_t>(), act_a.as<uint32_t>());
     hipLaunchKernelGGL(k_root, dim3(std::min<uint32_t>(blocks(n), 2048)), dim3(kBlock), 0, st, rec_a.as<Rec>(), n, nodes.as<BNode>(), counters.as<uint32_t>() + 3);
     BUILD_HIP(hipMemcpyAsync(h_cnt, counters.p, 16, hipMemcpyDeviceToHost, st));
@@ -563,7 +656,7 @@ int build_bvh_device(const std::vector<PrimInfo>& prims, HostBVH& out, hipStream
         *unsupported = true;
         return PT_OK;
     }
-    tick("records, alloc, upload");
+    tick("alloc, records, root");
     std::vector<uint32_t> level_start{0, 1};  // node ids of level L are [level_start[L], level_start[L + 1])
     uint32_t n_active = n > 2 ? 1 : 0;
     Buf *rc = &rec_a, *rn = &rec_b, *sc = &seg_a, *sn = &seg_b, *ac = &act_a, *an = &act_b;
@@ -578,9 +671,7 @@ int build_bvh_device(const std::vector<PrimInfo>& prims, HostBVH& out, hipStream
         hipLaunchKernelGGL(k_bin, dim3(blocks(n)), dim3(kBlock), 0, st, rc->as<Rec>(), sc->as<uint32_t>(), n, nodes.as<BNode>(), ac->as<uint32_t>(), bins.as<Bins>());
         hipLaunchKernelGGL(k_sah, dim3(blocks(n_active)), dim3(kBlock), 0, st, ac->as<uint32_t>(), n_active, nodes.as<BNode>(), bins.as<Bins>(), split.as<Split>());
         hipLaunchKernelGGL(k_flag, dim3(blocks(n)), dim3(kBlock), 0, st, rc->as<Rec>(), sc->as<uint32_t>(), n, split.as<Split>(), flags.as<uint32_t>());
-        hipLaunchKernelGGL(k_scan_sums, dim3(nb), dim3(kBlock), 0, st, flags.as<uint32_t>(), n, sums.as<uint32_t>());
-        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, st, sums.as<uint32_t>(), nb, P.as<uint32_t>(), n);
-        hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(kBlock), 0, st, flags.as<uint32_t>(), n, sums.as<uint32_t>(), P.as<uint32_t>());
+        scan_flags(flags.as<uint32_t>(), n, sums.as<uint32_t>(), P.as<uint32_t>(), st);
         BUILD_HIP(hipMemsetAsync(counters.as<uint32_t>() + 1, 0, 4, st));
         hipLaunchKernelGGL(k_children, dim3(blocks(n_active)), dim3(kBlock), 0, st, ac->as<uint32_t>(), n_active, nodes.as<BNode>(), split.as<Split>(), P.as<uint32_t>(),
                            counters.as<uint32_t>(), an->as<uint32_t>());
@@ -617,15 +708,59 @@ int build_bvh_device(const std::vector<PrimInfo>& prims, HostBVH& out, hipStream
         hipLaunchKernelGGL(k_number, dim3(blocks(level_start[L + 1] - level_start[L])), dim3(kBlock), 0, st, nodes.as<BNode>(), level_start[L], level_start[L + 1],
                            splits.as<uint32_t>(), event.as<uint32_t>(), newid.as<uint32_t>());
     hipLaunchKernelGGL(k_emit, dim3(blocks(n_nodes)), dim3(kBlock), 0, st, nodes.as<BNode>(), n_nodes, newid.as<uint32_t>(), outn.as<pt_bvh_node>());
-    out.nodes.resize(n_nodes);
-    out.indices.resize(n);
-    BUILD_HIP(hipMemcpyAsync(out.nodes.data(), outn.p, (size_t)n_nodes * sizeof(pt_bvh_node), hipMemcpyDeviceToHost, st));
-    BUILD_HIP(hipMemcpyAsync(out.indices.data(), final_idx.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     BUILD_HIP(hipStreamSynchronize(st));
     BUILD_HIP(hipGetLastError());
+    out.nodes = (pt_bvh_node*)outn.take();
+    out.indices = (uint32_t*)final_idx.take();
+    out.n_nodes = n_nodes;
+    out.n_prims = n;
     out.max_depth = levels;
     out.hazard = h_cnt[2] != 0;
-    tick("numbering, download");
+    tick("numbering");
+    return PT_OK;
+}
+
+int flatten_bvh_device(const DeviceTree& t, uint32_t big_from, DeviceFlat& out, hipStream_t st, std::string* err) {
+    const uint32_t nn = t.n_nodes;
+    Buf internal, big, pair_of, big_of, sums, root_ref, pairs, big_leaf;
+    BUILD_HIP(internal.alloc((size_t)nn * 4));
+    BUILD_HIP(big.alloc((size_t)nn * 4));
+    BUILD_HIP(pair_of.alloc(((size_t)nn + 1) * 4));
+    BUILD_HIP(big_of.alloc(((size_t)nn + 1) * 4));
+    BUILD_HIP(sums.alloc(((size_t)(nn + kScanTile - 1) / kScanTile) * 4));
+    BUILD_HIP(root_ref.alloc(4));
+    hipLaunchKernelGGL(k_node_flags, dim3(blocks(nn)), dim3(kBlock), 0, st, (const pt_bvh_node*)t.nodes, nn, big_from, internal.as<uint32_t>(), big.as<uint32_t>());
+    scan_flags(internal.as<uint32_t>(), nn, sums.as<uint32_t>(), pair_of.as<uint32_t>(), st);
+    scan_flags(big.as<uint32_t>(), nn, sums.as<uint32_t>(), big_of.as<uint32_t>(), st);
+    uint32_t counts[2] = {0, 0};
+    BUILD_HIP(hipMemcpyAsync(&counts[0], pair_of.as<uint32_t>() + nn, 4, hipMemcpyDeviceToHost, st));
+    BUILD_HIP(hipMemcpyAsync(&counts[1], big_of.as<uint32_t>() + nn, 4, hipMemcpyDeviceToHost, st));
+    BUILD_HIP(hipStreamSynchronize(st));
+    BUILD_HIP(pairs.alloc((size_t)counts[0] * sizeof(PairRecord)));
+    BUILD_HIP(big_leaf.alloc((size_t)counts[1] * 8));
+    hipLaunchKernelGGL(k_flatten, dim3(blocks(nn)), dim3(kBlock), 0, st, (const pt_bvh_node*)t.nodes, nn, pair_of.as<uint32_t>(), big_of.as<uint32_t>(), big_from,
+                       pairs.as<PairRecord>(), big_leaf.as<uint32_t>(), root_ref.as<uint32_t>());
+    pt_bvh_node root;
+    BUILD_HIP(hipMemcpyAsync(&out.root_ref, root_ref.p, 4, hipMemcpyDeviceToHost, st));
+    BUILD_HIP(hipMemcpyAsync(&root, t.nodes, sizeof(root), hipMemcpyDeviceToHost, st));
+    BUILD_HIP(hipStreamSynchronize(st));
+    BUILD_HIP(hipGetLastError());
+    for (int a = 0; a < 3; ++a) { out.root_min[a] = root.min[a]; out.root_max[a] = root.max[a]; }
+    out.pairs_bytes = std::max<size_t>((size_t)counts[0] * sizeof(PairRecord), 16);
+    out.big_bytes = std::max<size_t>((size_t)counts[1] * 8, 16);
+    out.pairs = pairs.take();
+    out.big_leaf = big_leaf.take();
+    return PT_OK;
+}
+
+int download_tree(const DeviceTree& t, HostBVH& out, hipStream_t st, std::string* err) {
+    out.nodes.resize(t.n_nodes);
+    out.indices.resize(t.n_prims);
+    BUILD_HIP(hipMemcpyAsync(out.nodes.data(), t.nodes, (size_t)t.n_nodes * sizeof(pt_bvh_node), hipMemcpyDeviceToHost, st));
+    BUILD_HIP(hipMemcpyAsync(out.indices.data(), t.indices, (size_t)t.n_prims * 4, hipMemcpyDeviceToHost, st));
+    BUILD_HIP(hipStreamSynchronize(st));
+    out.max_depth = t.max_depth;
+    out.hazard = t.hazard;
     return PT_OK;
 }
 
