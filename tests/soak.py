@@ -52,12 +52,13 @@ def main():
     SCALE = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     sky = scenes.make_sky()
     t_end = time.time() + 60 * minutes
-    rounds = 0
+    rounds = device_builds = 0
     while time.time() < t_end:
         seed = seed0 + rounds
         rng = np.random.default_rng(seed)
         name, scene = draw_scene(rng)
         g = ptcore.PathTracer(0).set_scene(scene, sky)
+        device_builds += int(g.build_info()[0])
         o = orc.from_scene(scene, sky)
         what = "bvh"
         ok = all(a.tobytes() == b.tobytes() for a, b in zip(g.bvh()[:2], o.bvh()[:2]))
@@ -109,7 +110,7 @@ def main():
         print(("ok   " if ok else "DIFF ") + "seed %d %s %s" % (seed, name, what), flush=True)
         if not ok:
             sys.exit(1)
-    print("soak: %d rounds, no difference" % rounds)
+    print("soak: %d rounds (%d trees built on the GPU, the others by the host build), no difference" % (rounds, device_builds))
 
 
 if __name__ == "__main__":
