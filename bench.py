@@ -258,7 +258,10 @@ def main():
     make, W, H, cam_o, cam_t, desc = workloads(scenes)[args.workload]
     scene = make()
     sky = scenes.make_sky()
+    t_build = time.perf_counter()
     g = ptcore.PathTracer(device).set_scene(scene, sky)
+    t_build = time.perf_counter() - t_build
+    built_on_device, tree_ms = g.build_info()
     g.set_camera(cam_o, cam_t, W, H)
     g.set_option(ptcore.OPT_RENDER_MODE, 1 if args.mode == "path" else 0)
     seed = 2026
@@ -376,6 +379,8 @@ def main():
             "mpaths_per_s": paths_all / dt_max / 1e6,
             "rays_per_path": rays_all / max(paths_all, 1),
             "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
+            "scene_setup": {"tree_built_on": "gpu" if built_on_device else "host", "tree_ms": tree_ms, "upload_build_flatten_ms": t_build * 1e3,
+                            "note": "outside the timed region: objects + sky uploaded, the reference's BVH built, flattened, primitives put in leaf order"},
         }
         if one_gpu:
             out["rehearsal"] = f"{world} ranks on ONE GPU over gloo (collectives staged through the host): a functional check, not a scaling number"
