@@ -180,24 +180,35 @@ __global__ void k_init_bins(Bins* bins, uint32_t n_active) {
     ((uint32_t*)bins)[i] = w < 72 ? kKeyPosInf : (w < 144 ? kKeyNegInf : 0u);
 }
 
-// ---- binning.  A block whose positions all belong to one node reduces in LDS first.
+// ---- binning.  Positions of one node are contiguous, so a whole workgroup or at least a whole wave usually lies inside
+// one node: such a wave reduces into its own LDS bins, which are flushed with one global atomic per touched word (per
+// workgroup when all of it is one node).  Only waves that straddle nodes update the global bins per primitive.
+constexpr int kWaves = kBlock / 64;
+
+__device__ __forceinline__ uint32_t bin_identity(int w) { return w < 72 ? kKeyPosInf : (w < 144 ? kKeyNegInf : 0u); }
+__device__ __forceinline__ void bin_flush(uint32_t* g, int w, uint32_t v) {
+    if (w < 72) { if (v != kKeyPosInf) atomicMin(g + w, v); }
+    else if (w < 144) { if (v != kKeyNegInf) atomicMax(g + w, v); }
+    else if (v) atomicAdd(g + w, v);
+}
+
 __global__ void k_bin(const Rec* __restrict__ rec, const uint32_t* __restrict__ seg, uint32_t n, const BNode* __restrict__ nodes,
                       const uint32_t* __restrict__ active, Bins* bins) {
-    __shared__ uint32_t lb[kBinWords];
+    __shared__ uint32_t lb[kWaves][kBinWords];
     __shared__ uint32_t s0;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t s = i < n ? seg[i] : kNone;
     if (threadIdx.x == 0) s0 = s;
+    for (int w = threadIdx.x; w < kWaves * kBinWords; w += blockDim.x) (&lb[0][0])[w] = bin_identity(w % kBinWords);
     __syncthreads();
-    const uint32_t first_s = s0;
-    const bool uniform = __syncthreads_and((i >= n || s == first_s) ? 1 : 0) != 0 && first_s != kNone;
-    if (uniform)
-        for (int w = threadIdx.x; w < kBinWords; w += blockDim.x) lb[w] = w < 72 ? kKeyPosInf : (w < 144 ? kKeyNegInf : 0u);
-    __syncthreads();
+    const uint32_t block_s = s0, wave_s = __shfl(s, 0, 64);
+    const bool block_uniform = __syncthreads_and((i >= n || s == block_s) ? 1 : 0) != 0 && block_s != kNone;
+    const bool wave_uniform = __all((i >= n || s == wave_s) ? 1 : 0) != 0 && wave_s != kNone;
     if (s != kNone) {
         const BNode& nd = nodes[active[s]];
         const Rec r = rec[i];
-        Bins* B = uniform ? (Bins*)lb : bins + s;
+        Bins* B = wave_uniform ? (Bins*)lb[wave] : bins + s;
         for (int a = 0; a < 3; ++a) {
             const float lo = key2f(nd.cmin[a]), hi = key2f(nd.cmax[a]);
             const float delta = (hi - lo) / 8.0f;                 // bvh.rs:121-123
@@ -210,15 +221,17 @@ __global__ void k_bin(const Rec* __restrict__ rec, const uint32_t* __restrict__ 
             atomicAdd(&B->n[b], 1u);
         }
     }
-    if (uniform) {
-        __syncthreads();
-        uint32_t* g = (uint32_t*)(bins + first_s);
+    __syncthreads();
+    if (block_uniform) {  // every wave is inside the one node (or past the end): combine the slices, one flush
+        uint32_t* g = (uint32_t*)(bins + block_s);
         for (int w = threadIdx.x; w < kBinWords; w += blockDim.x) {
-            const uint32_t v = lb[w];
-            if (w < 72) { if (v != kKeyPosInf) atomicMin(g + w, v); }
-            else if (w < 144) { if (v != kKeyNegInf) atomicMax(g + w, v); }
-            else if (v) atomicAdd(g + w, v);
+            uint32_t v = lb[0][w];
+            for (int k = 1; k < kWaves; ++k) v = w < 72 ? min(v, lb[k][w]) : (w < 144 ? max(v, lb[k][w]) : v + lb[k][w]);
+            bin_flush(g, w, v);
         }
+    } else if (wave_uniform) {
+        uint32_t* g = (uint32_t*)(bins + wave_s);
+        for (int w = lane; w < kBinWords; w += 64) bin_flush(g, w, lb[wave][w]);
     }
 }
 
@@ -395,22 +408,22 @@ __global__ void k_lpos(const uint32_t* __restrict__ seg, uint32_t n, const uint3
     lpos[first + (P[i] - P[first])] = i - first;
 }
 
-// one pass: every active primitive to its place in the next level, child bounds reduced on the way
+// one pass: every active primitive to its place in the next level, child bounds reduced on the way (per wave or per
+// workgroup in LDS when it lies inside one node, as in k_bin)
 __global__ void k_scatter(const Rec* __restrict__ rec, const uint32_t* __restrict__ seg, uint32_t n, const uint32_t* __restrict__ flags,
                           const uint32_t* __restrict__ P, const uint32_t* __restrict__ lpos, const uint32_t* __restrict__ active, BNode* nodes,
                           const Split* __restrict__ split, Rec* rec_next, uint32_t* seg_next, uint32_t* final_idx) {
-    __shared__ uint32_t acc[24];  // [child][bmin3 bmax3 cmin3 cmax3]
-    __shared__ uint32_t s0, pair_sh;
+    __shared__ uint32_t acc[kWaves][24];  // [child][bmin3 bmax3 cmin3 cmax3]
+    __shared__ uint32_t s0;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t s = i < n ? seg[i] : kNone;
     if (threadIdx.x == 0) s0 = s;
+    if (threadIdx.x < kWaves * 24) (&acc[0][0])[threadIdx.x] = (threadIdx.x % 6) < 3 ? kKeyPosInf : kKeyNegInf;
     __syncthreads();
-    const uint32_t first_s = s0;
-    const bool uniform = __syncthreads_and((i >= n || s == first_s) ? 1 : 0) != 0 && first_s != kNone;
-    if (uniform && threadIdx.x < 24) acc[threadIdx.x] = (threadIdx.x % 6) < 3 ? kKeyPosInf : kKeyNegInf;
-    __syncthreads();
-    uint32_t pair = 0;
-    bool did_split = false;
+    const uint32_t block_s = s0, wave_s = __shfl(s, 0, 64);
+    const bool block_uniform = __syncthreads_and((i >= n || s == block_s) ? 1 : 0) != 0 && block_s != kNone;
+    const bool wave_uniform = __all((i >= n || s == wave_s) ? 1 : 0) != 0 && wave_s != kNone;
     if (i < n) {
         if (s == kNone) {
             seg_next[i] = kNone;
@@ -421,8 +434,6 @@ __global__ void k_scatter(const Rec* __restrict__ rec, const uint32_t* __restric
                 final_idx[i] = r.idx;
                 seg_next[i] = kNone;
             } else {
-                did_split = true;
-                pair = sp.pair;
                 const uint32_t first = nodes[active[s]].first;
                 uint32_t q;
                 if (flags[i]) {
@@ -437,7 +448,7 @@ __global__ void k_scatter(const Rec* __restrict__ rec, const uint32_t* __restric
                 if (cs == kNone) final_idx[dest] = r.idx;  // a child of one or two primitives is never split
                 else rec_next[dest] = r;
                 seg_next[dest] = cs;
-                uint32_t* b = uniform ? acc + 12 * right : nodes[pair + right].bmin;  // bmin, bmax, cmin, cmax are consecutive
+                uint32_t* b = wave_uniform ? acc[wave] + 12 * right : nodes[sp.pair + right].bmin;  // bmin, bmax, cmin, cmax are consecutive
                 for (int a = 0; a < 3; ++a) {
                     atomicMin(b + a, f2key(r.mn[a]));
                     atomicMax(b + 3 + a, f2key(r.mx[a]));
@@ -447,16 +458,26 @@ __global__ void k_scatter(const Rec* __restrict__ rec, const uint32_t* __restric
             }
         }
     }
-    if (uniform) {
-        if (threadIdx.x == 0) pair_sh = 0;
-        __syncthreads();
-        if (did_split) pair_sh = pair;  // same value from every thread of a uniform block
-        __syncthreads();
-        if (threadIdx.x < 24 && pair_sh) {
-            const uint32_t v = acc[threadIdx.x];
-            uint32_t* dst = nodes[pair_sh + threadIdx.x / 12].bmin + threadIdx.x % 12;
-            if ((threadIdx.x % 6) < 3) { if (v != kKeyPosInf) atomicMin(dst, v); }
-            else if (v != kKeyNegInf) atomicMax(dst, v);
+    __syncthreads();
+    // flush: the untouched identities are skipped, so a node that did not split (nothing accumulated) writes nothing
+    if (block_uniform) {
+        if (threadIdx.x < 24) {
+            const bool is_min = (threadIdx.x % 6) < 3;
+            uint32_t v = acc[0][threadIdx.x];
+            for (int k = 1; k < kWaves; ++k) v = is_min ? min(v, acc[k][threadIdx.x]) : max(v, acc[k][threadIdx.x]);
+            if (v != (is_min ? kKeyPosInf : kKeyNegInf)) {
+                uint32_t* dst = nodes[split[block_s].pair + threadIdx.x / 12].bmin + threadIdx.x % 12;
+                if (is_min) atomicMin(dst, v);
+                else atomicMax(dst, v);
+            }
+        }
+    } else if (wave_uniform && lane < 24) {
+        const bool is_min = (lane % 6) < 3;
+        const uint32_t v = acc[wave][lane];
+        if (v != (is_min ? kKeyPosInf : kKeyNegInf)) {
+            uint32_t* dst = nodes[split[wave_s].pair + lane / 12].bmin + lane % 12;
+            if (is_min) atomicMin(dst, v);
+            else atomicMax(dst, v);
         }
     }
 }
