@@ -135,6 +135,39 @@ def test_device_build_equals_host_build(ptcore, sky):
         g.close()
 
 
+def test_device_built_scene_renders_like_host_built_scene(ptcore, sky):
+    """Flattening and the leaf-order gather also run on the device after a device build (k_flatten, k_reorder_*), and
+    number the large-leaf table in node order instead of parent order: hits, frames and the tree read back lazily
+    must not depend on which side built — on a scene with leaves of hundreds of triangles, several lights, and spheres."""
+    rng = np.random.default_rng(23)
+    n = 4000
+    ctr = rng.uniform(-1, 1, size=(n, 3)) * [1, 0.4, 1] + [0.7, 0.2, 0.6]
+    a, b = rng.normal(size=(n, 3)) * 0.4, rng.normal(size=(n, 3)) * 0.4
+    tri = np.concatenate([ctr, ctr + a, ctr + b], axis=1).astype(np.float32)
+    tri[:400] = tri[0]       # one leaf of 400
+    tri[400:460] = tri[400]  # one of 60
+    tri[460:480] = tri[460]  # one of 20
+    rows = [scenes.GLASS_BLUE, scenes.diffuse(1.5, (0.7, 0.6, 0.5)), scenes.emissive()]
+    mesh = scenes.wrap_mesh(tri, scenes._flat_normals(tri), rng.integers(0, 3, n).astype(np.uint32), rows)
+    cr = np.concatenate([rng.uniform(-1, 1, size=(300, 3)) + [0.7, 0.5, 0.6], rng.uniform(0.02, 0.2, size=(300, 1))], axis=1).astype(np.float32)
+    balls = (cr, rng.integers(0, 3, 300).astype(np.uint32), scenes.materials(rows))
+    rays = scenes.random_rays(30000, seed=9, aim=(0.7, 0.2, 0.6))
+    for scene in (mesh, balls):
+        got = {}
+        for on in (1, 0):
+            g = ptcore.PathTracer(0)
+            g.set_option(ptcore.OPT_DEVICE_BUILD, on)
+            g.set_scene(scene, sky)
+            assert g.build_info()[0] == bool(on)
+            g.set_camera(scenes.CAMERA_ORIGIN, scenes.CAMERA_TARGET, 96, 64)
+            g.render(3, 32, seed=5)
+            hits = [g.trace(rays, any_hit).tobytes() for any_hit in (False, True)]
+            nodes, idx, depth = g.bvh()   # after rendering: a device-built tree is only now fetched
+            got[on] = (g.read_accum()[0].tobytes(), hits, nodes.tobytes(), idx.tobytes(), depth, float(g.camera()["focal_distance"]))
+            g.close()
+        assert got[1] == got[0]
+
+
 @pytest.mark.parametrize("name", list(SCENES))
 @pytest.mark.parametrize("any_hit", [False, True])
 def test_trace_bit_exact(pairs, name, any_hit):
