@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "pt_build.h"
+#include "pt_kernels.h"
 
 #pragma clang fp contract(off)
 
@@ -520,7 +521,7 @@ __global__ void k_reorder_tri(const float* __restrict__ pos, const float* __rest
     if (s >= n) return;
     const uint32_t obj = idx[s];
     const float* p = pos + 9 * (size_t)obj;
-    float* r = prim + 12 * (size_t)s;
+    float* r = prim + 4 * (size_t)kTriStride * s;
     const float p0[3] = {p[0], p[1], p[2]};
     for (int k = 0; k < 3; ++k) {
         r[k] = p0[k];

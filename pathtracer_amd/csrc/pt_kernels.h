@@ -14,7 +14,7 @@ enum { PRIM_TRIANGLE = 0, PRIM_SPHERE = 1 };
 // Read-only scene data resident in HBM (replicated per GPU).  See DESIGN.md "Data layout".
 struct DevScene {
     const float4* pairs;       // 4 x float4 (64 B) per internal node: {Lmin,Lref}{Lmax,0}{Rmin,Rref}{Rmax,0}
-    const float4* prim;        // triangles: 3 x float4 per slot {p0.xyz,e1.x}{e1.yz,e2.xy}{e2.z,id,mat,0}
+    const float4* prim;        // triangles: kTriStride (4) x float4 per slot {p0.xyz,e1.x}{e1.yz,e2.xy}{e2.z,id,mat,0}{unused}
                                // spheres:   1 x float4 per slot {c.xyz, r}
     const uint32_t* prim_meta; // spheres: 2 x u32 per slot {object id, material}
     const float* nrm;          // triangles: 9 floats per slot (normal0..2), leaf order
@@ -68,10 +68,15 @@ struct LaunchCfg {
 #ifndef PT_WAVES_PER_CU
 #define PT_WAVES_PER_CU 24
 #endif
+#ifndef PT_TRI_STRIDE
+#define PT_TRI_STRIDE 4
+#endif
 #ifndef PT_COOP_LEAF_FROM
 #define PT_COOP_LEAF_FROM 16
 #endif
 constexpr uint32_t kCoopLeafFrom = PT_COOP_LEAF_FROM;  // triangle leaves of at least this many primitives are tested by the whole wave (0 = never)
+constexpr int kTriStride = PT_TRI_STRIDE;     // float4 per triangle slot: 4 = one 64-byte sector each (the record is 48 B; packed, every other
+                                              // one straddled two sectors: C3 +0.9 %, C5 +1.2 %, profiles/r2_ab_triangle_record_64B.txt)
 constexpr int kTraceBlock = PT_TRACE_BLOCK;  // threads per traversal workgroup
 constexpr int kLdsStack = PT_LDS_STACK;      // stack entries per lane kept in LDS
 constexpr int kWavesPerCU = PT_WAVES_PER_CU; // persistent grid: waves launched per CU (what fits is decided by LDS and VGPRs)

@@ -120,7 +120,7 @@ __device__ __forceinline__ void traverse(const DevScene& S, V3 o, V3 d, float& d
             for (uint32_t k = 0; k < count; ++k) {
                 const uint32_t slot = first + k;
                 if (PRIM == PRIM_TRIANGLE) {
-                    const float4* tp = S.prim + (size_t)slot * 3;
+                    const float4* tp = S.prim + (size_t)slot * kTriStride;
                     const float4 a = tp[0], b = tp[1], c = tp[2];
                     float t, u, v, det;
                     if (tri_hit(V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, V3{b.z, b.w, c.x}, o, d, &t, &u, &v, &det)) {
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DevScene S, const pt_ray*
         out.t = dist;
         out.inside = 0;
         if (h.slot != PT_MISS) {
-            out.prim = PRIM == PRIM_TRIANGLE ? __float_as_uint(S.prim[(size_t)h.slot * 3 + 2].y) : S.prim_meta[2 * h.slot];
+            out.prim = PRIM == PRIM_TRIANGLE ? __float_as_uint(S.prim[(size_t)h.slot * kTriStride + 2].y) : S.prim_meta[2 * h.slot];
             out.inside = h.inside;
         }
         hits[i] = out;
@@ -219,7 +219,7 @@ template <int PRIM>
 __device__ __forceinline__ Surface surface_at(const DevScene& S, uint32_t slot, float u, float v, V3 o, V3 d, float t, bool want_area) {
     Surface s;
     if (PRIM == PRIM_TRIANGLE) {
-        const float4* tp = S.prim + (size_t)slot * 3;
+        const float4* tp = S.prim + (size_t)slot * kTriStride;
         const float4 a = tp[0], b = tp[1], c = tp[2];
         const float* n = S.nrm + (size_t)slot * 9;
         s.normal = tri_normal(ld3(n), ld3(n + 3), ld3(n + 6), u, v);
@@ -571,7 +571,7 @@ __device__ __forceinline__ void step_internal(const DevScene& S, LaneTrav& T, bo
 template <int PRIM>
 __device__ __forceinline__ void test_prim(const DevScene& S, LaneTrav& T, uint32_t ps) {
     if (PRIM == PRIM_TRIANGLE) {
-        const float4* tp = S.prim + (size_t)ps * 3;
+        const float4* tp = S.prim + (size_t)ps * kTriStride;
         const float4 a = tp[0], b = tp[1], c = tp[2];
         float t, u, v, det;
         if (tri_hit(V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, V3{b.z, b.w, c.x}, T.o, T.d, &t, &u, &v, &det)) {
@@ -674,7 +674,7 @@ __device__ __forceinline__ void step_prim_wave(const DevScene& S, LaneTrav& T, b
             float t = 0.f, u = 0.f, v = 0.f, det = 0.f;
             bool hit = false;
             if (k < n) {
-                const float4* tp = S.prim + (size_t)(f + k) * 3;
+                const float4* tp = S.prim + (size_t)(f + k) * kTriStride;
                 const float4 a = tp[0], b = tp[1], c = tp[2];
                 hit = tri_hit(V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, V3{b.z, b.w, c.x}, o, d, &t, &u, &v, &det);
             }
@@ -840,7 +840,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_extend_pw(DevScene S, PathState
 
 template <int PRIM>
 __device__ __forceinline__ uint32_t prim_material(const DevScene& S, uint32_t slot) {
-    return PRIM == PRIM_TRIANGLE ? __float_as_uint(S.prim[(size_t)slot * 3 + 2].z) : S.prim_meta[2 * slot + 1];
+    return PRIM == PRIM_TRIANGLE ? __float_as_uint(S.prim[(size_t)slot * kTriStride + 2].z) : S.prim_meta[2 * slot + 1];
 }
 
 // The state of one path between two traces — what Camera::sample keeps in locals
@@ -939,7 +939,7 @@ __device__ __forceinline__ bool shade_core(const DevScene& S, PathVals& pv, cons
                 float larea, gdist = kInf;
                 bool lhit;
                 if (PRIM == PRIM_TRIANGLE) {
-                    const float4* tpp = S.prim + (size_t)lslot * 3;
+                    const float4* tpp = S.prim + (size_t)lslot * kTriStride;
                     const float4 a = tpp[0], b = tpp[1], c = tpp[2];
                     const V3 p0 = V3{a.x, a.y, a.z}, e1 = V3{a.w, b.x, b.y}, e2 = V3{b.z, b.w, c.x};
                     const float u = open01(rn.v[1]);
