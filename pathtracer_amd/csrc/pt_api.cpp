@@ -586,7 +586,7 @@ static int finalize_scene(pt_ctx* c, RawGeom& raw) {
         if ((rc = dev_alloc(c, d_slot, n * sizeof(uint32_t)))) return rc;
         if (c->prim_kind == PRIM_TRIANGLE) {
             if ((rc = dev_alloc(c, c->d_prim, 4 * (size_t)kTriStride * n * sizeof(float)))) return rc;
-            if ((rc = dev_alloc(c, c->d_nrm, 9 * n * sizeof(float)))) return rc;
+            if ((rc = dev_alloc(c, c->d_nrm, (size_t)kNrmStride * n * sizeof(float)))) return rc;
             if ((rc = dev_alloc(c, c->d_meta, 16))) return rc;
             launch_reorder_triangles((const float*)raw.a.p, (const float*)raw.b.p, (const uint32_t*)raw.mat.p, d_idx, n32, (float*)c->d_prim.p,
                                      (float*)c->d_nrm.p, (uint32_t*)d_slot.p, c->stream);

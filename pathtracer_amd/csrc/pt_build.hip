@@ -531,7 +531,13 @@ __global__ void k_reorder_tri(const float* __restrict__ pos, const float* __rest
     r[9] = __uint_as_float(obj);
     r[10] = __uint_as_float(mat[obj]);
     r[11] = 0.0f;
-    for (int k = 0; k < 9; ++k) nrm_out[9 * (size_t)s + k] = nrm[9 * (size_t)obj + k];
+    if (kNrmStride == 16) {
+        for (int v = 0; v < 3; ++v)
+            for (int k = 0; k < 4; ++k) nrm_out[16 * (size_t)s + 4 * v + k] = k < 3 ? nrm[9 * (size_t)obj + 3 * v + k] : 0.0f;
+        for (int k = 12; k < 16; ++k) nrm_out[16 * (size_t)s + k] = 0.0f;
+    } else {
+        for (int k = 0; k < 9; ++k) nrm_out[9 * (size_t)s + k] = nrm[9 * (size_t)obj + k];
+    }
     slot_of[obj] = s;
 }
 

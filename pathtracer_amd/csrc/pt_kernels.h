@@ -71,12 +71,17 @@ struct LaunchCfg {
 #ifndef PT_TRI_STRIDE
 #define PT_TRI_STRIDE 4
 #endif
+#ifndef PT_NRM_STRIDE
+#define PT_NRM_STRIDE 9
+#endif
 #ifndef PT_COOP_LEAF_FROM
 #define PT_COOP_LEAF_FROM 16
 #endif
 constexpr uint32_t kCoopLeafFrom = PT_COOP_LEAF_FROM;  // triangle leaves of at least this many primitives are tested by the whole wave (0 = never)
 constexpr int kTriStride = PT_TRI_STRIDE;     // float4 per triangle slot: 4 = one 64-byte sector each (the record is 48 B; packed, every other
                                               // one straddled two sectors: C3 +0.9 %, C5 +1.2 %, profiles/r2_ab_triangle_record_64B.txt)
+constexpr int kNrmStride = PT_NRM_STRIDE;     // floats per slot of the normals array: 9 = packed; 16 = {n0,_}{n1,_}{n2,_}{_} in one 64-byte sector
+                                              // measured 0.5 % slower on C3 / C4 (profiles/r2_ab_normal_record_64B.txt): shading reads them once per hit
 constexpr int kTraceBlock = PT_TRACE_BLOCK;  // threads per traversal workgroup
 constexpr int kLdsStack = PT_LDS_STACK;      // stack entries per lane kept in LDS
 constexpr int kWavesPerCU = PT_WAVES_PER_CU; // persistent grid: waves launched per CU (what fits is decided by LDS and VGPRs)

@@ -215,14 +215,23 @@ struct Surface {
     float area;
     uint32_t mat;
 };
+__device__ __forceinline__ V3 tri_normal_at(const DevScene& S, uint32_t slot, float u, float v) {
+    if (kNrmStride == 16) {
+        const float4* n = (const float4*)S.nrm + (size_t)slot * 4;
+        const float4 a = n[0], b = n[1], c = n[2];
+        return tri_normal(V3{a.x, a.y, a.z}, V3{b.x, b.y, b.z}, V3{c.x, c.y, c.z}, u, v);
+    }
+    const float* n = S.nrm + (size_t)slot * 9;
+    return tri_normal(ld3(n), ld3(n + 3), ld3(n + 6), u, v);
+}
+
 template <int PRIM>
 __device__ __forceinline__ Surface surface_at(const DevScene& S, uint32_t slot, float u, float v, V3 o, V3 d, float t, bool want_area) {
     Surface s;
     if (PRIM == PRIM_TRIANGLE) {
         const float4* tp = S.prim + (size_t)slot * kTriStride;
         const float4 a = tp[0], b = tp[1], c = tp[2];
-        const float* n = S.nrm + (size_t)slot * 9;
-        s.normal = tri_normal(ld3(n), ld3(n + 3), ld3(n + 6), u, v);
+        s.normal = tri_normal_at(S, slot, u, v);
         s.mat = __float_as_uint(c.z);
         s.area = want_area ? tri_area(V3{a.w, b.x, b.y}, V3{b.z, b.w, c.x}) : 0.0f;
     } else {
@@ -952,8 +961,7 @@ __device__ __forceinline__ bool shade_core(const DevScene& S, PathVals& pv, cons
                     lhit = tri_hit(p0, e1, e2, go, ldir, &tt, &uu, &vv, &det);
                     if (lhit) {
                         gdist = tt;
-                        const float* n = S.nrm + (size_t)lslot * 9;
-                        ln = tri_normal(ld3(n), ld3(n + 3), ld3(n + 6), uu, vv);
+                        ln = tri_normal_at(S, lslot, uu, vv);
                         larea = tri_area(e1, e2);
                     }
                 } else {
