@@ -140,9 +140,8 @@ int pt_set_sky(pt_ctx *ctx, const float *rgb, uint32_t w, uint32_t h);
 
 /* BVH::new (src/bvh.rs:25-179): binned-SAH build, bit-identical tree and leaf order, then flattening + upload.
  * Also collects the lights list (src/bvh.rs:29-35).  The tree is built on the GPU, one level at a time (SURVEY 8f row
- * N3; PT_OPT_DEVICE_BUILD, default 1), or by the threaded host build when the option is 0 or when a primitive's
- * centre or bounds hold a negative zero, an infinity or a NaN (a min / max over such values depends on the operand
- * order, which only the host build reproduces).  Same tree either way. */
+ * N3; PT_OPT_DEVICE_BUILD, default 1), or by the threaded host build when the option is 0.  Same tree either way,
+ * negative zeros, infinities and NaNs in the coordinates included. */
 int pt_build(pt_ctx *ctx);
 /* what the last pt_build did: *on_device = 1 when the tree was built on the GPU; *build_ms = the tree build alone
  * (host or device, without flattening and upload).  No counterpart in the reference. */
@@ -257,7 +256,7 @@ int pt_sample_skybox(pt_ctx *ctx, const float *dirs, uint64_t n, float *rgb);
  *  PT_OPT_TAIL_MODE       0 = fused phase-scheduled tail kernel, 1 = further rounds on the tail stream with a small
  *                         grid, 2 = fused tail kernel that traces and shades in lock step
  *  PT_OPT_SIMPLE_EXTEND   1 = one-ray-per-lane traversal kernel instead of the persistent one (A/B, tests)
- *  PT_OPT_DEVICE_BUILD    1 = pt_build builds the tree on the GPU when the input allows it (default), 0 = always on the host
+ *  PT_OPT_DEVICE_BUILD    1 = pt_build builds the tree on the GPU (default), 0 = on the host (threads)
  *  PT_OPT_MERGE_QUEUED_CALLS  a pt_render_async call that continues the newest queued call (same frame, depth, seed,
  *                         shard and flags, the next sample indices) while that call has not started yet is added to it, up
  *                         to this many paths per merged call (default 128 Mi; 0 = never merge).  Same results, fewer and

@@ -408,25 +408,22 @@ int pt_build(pt_ctx* c) {
     c->dtree.release();
     c->build_on_device = false;
     c->built = false;
-    if (c->opt_device_build) {  // same tree either way; inputs the device build cannot order (-0, inf, NaN) go to the host build
+    if (c->opt_device_build) {  // same tree either way
         const auto t_up = std::chrono::steady_clock::now();
         if (int rc = upload_geometry(c, raw)) return rc;
         tick("upload objects", t_up);
         const auto t0 = std::chrono::steady_clock::now();
-        bool unsupported = false;
         std::string why;
-        if (int rc = build_bvh_device(c->prim_kind == PRIM_TRIANGLE ? 0 : 1, (const float*)raw.a.p, (uint32_t)n, c->dtree, c->stream, &unsupported, &why))
+        if (int rc = build_bvh_device(c->prim_kind == PRIM_TRIANGLE ? 0 : 1, (const float*)raw.a.p, (uint32_t)n, c->dtree, c->stream, &why))
             return c->fail(rc, why);
-        c->build_on_device = !unsupported;
-        if (c->build_on_device) {
-            c->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            tick("tree (device)", t0);
-            c->host_bvh_current = false;
-            c->bvh.nodes.clear();
-            c->bvh.indices.clear();
-            c->bvh.max_depth = c->dtree.max_depth;
-            c->bvh.hazard = c->dtree.hazard;
-        }
+        c->build_on_device = true;
+        c->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        tick("tree (device)", t0);
+        c->host_bvh_current = false;
+        c->bvh.nodes.clear();
+        c->bvh.indices.clear();
+        c->bvh.max_depth = c->dtree.max_depth;
+        c->bvh.hazard = c->dtree.hazard;
     }
     if (!c->build_on_device) {
         const auto t0 = std::chrono::steady_clock::now();

@@ -29,10 +29,9 @@ struct DeviceFlat {
 };
 
 // Builds the tree on the current device from geometry that is already there (prim_kind 0: n x 9 triangle positions,
-// 1: n x 4 spheres); work is enqueued on `st` and has finished on return.  *unsupported = true (and nothing built) when
-// an input value is a negative zero, infinite or NaN: min / max of such values depend on operand order, which only
-// the host build reproduces.
-int build_bvh_device(int prim_kind, const float* d_geom, uint32_t n, DeviceTree& out, hipStream_t st, bool* unsupported, std::string* err);
+// 1: n x 4 spheres); work is enqueued on `st` and has finished on return.  Negative zeros, infinities and NaNs in the
+// input give the reference's result too (pt_build.hip, header comment).
+int build_bvh_device(int prim_kind, const float* d_geom, uint32_t n, DeviceTree& out, hipStream_t st, std::string* err);
 // flatten_bvh() of pt_bvh.h on the device (pair records in node order; big-leaf slots in node order)
 int flatten_bvh_device(const DeviceTree& t, uint32_t big_from, DeviceFlat& out, hipStream_t st, std::string* err);
 // nodes + indices to the host (pt_get_bvh)

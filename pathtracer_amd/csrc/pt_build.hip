@@ -14,9 +14,12 @@
 //              bounds (and the children's centre bounds for the next level) are reduced in the same pass.
 // Bounds are mins / maxes of input values (exact in any order), counts are integers, and the few float operations
 // (delta, bin number, areas, costs, pivot) are the same single IEEE operations in the same order as on the host
-// (-ffp-contract=off).  The one thing an unordered reduction cannot reproduce is which ZERO wins min(+0, -0), and NaN
-// bounds would need the reference's operand order too: inputs holding a negative zero or a non-finite value are
-// reported as unsupported and the caller builds on the host.
+// (-ffp-contract=off).  Two things depend on the ORDER of a min / max chain in the reference (f32::min / max: the
+// non-NaN operand wins, the first operand wins a tie): NaNs are simply never taken, so they are skipped here too; and
+// min(+0, -0) is the zero that came first.  No decision of the build can see the sign of a zero (areas, costs, bin
+// numbers and the <= against the pivot come out the same), so zeros are reduced as one value and the sign of a node
+// bound that ends up zero is settled separately: the object with a zero there that the reference's walk meets first
+// (smallest position at the time of the walk) decides it.
 // Numbering: the reference appends a node's two children when it splits the node, and splits in depth-first order, left
 // subtree first.  With s(v) = number of splits in v's subtree, the split of v's left child is event e(v) + 1 and the
 // right child's e(v) + 1 + s(left); children of the node split at event e are nodes 1 + 2e and 2 + 2e.
@@ -44,12 +47,19 @@ constexpr uint32_t kKeyPosInf = 0xff800000u;  // key(+inf): identity of min
 constexpr uint32_t kKeyNegInf = 0x007fffffu;  // key(-inf): identity of max
 constexpr int kBlock = 256;
 
-// order-preserving map float -> uint32 (total order of finite values and infinities; -0 < +0, which is why inputs with
-// a negative zero are refused)
+// order-preserving map float -> uint32 (finite values and infinities; both zeros share a key, zero_vote() keeps their sign)
 __device__ __forceinline__ uint32_t f2key(float f) {
-    const uint32_t u = __float_as_uint(f);
+    uint32_t u = __float_as_uint(f);
+    if (u == 0x80000000u) u = 0;  // one key for both zeros
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
+// f32::min / max of the reference (pt_bvh.cpp mn2 / mx2): the non-NaN operand wins, the first wins a tie
+__device__ __forceinline__ float rmin(float a, float b) { return a != a ? b : (b < a ? b : a); }
+__device__ __forceinline__ float rmax(float a, float b) { return a != a ? b : (b > a ? b : a); }
+__device__ __forceinline__ void key_min(uint32_t* dst, float v) { if (v == v) atomicMin(dst, f2key(v)); }  // a NaN is never taken
+__device__ __forceinline__ void key_max(uint32_t* dst, float v) { if (v == v) atomicMax(dst, f2key(v)); }
+// who decides the sign of a zero bound: smallest (position << 1 | sign bit) among the objects with a zero there
+__device__ __forceinline__ void zero_vote(uint32_t* dst, float v, uint32_t pos) { if (v == 0.0f) atomicMin(dst, (pos << 1) | (__float_as_uint(v) >> 31)); }
 __device__ __forceinline__ float key2f(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
 
 struct Rec {  // pt_bvh.cpp's record: bvh.indices[i] with that object's centre and bounds
@@ -57,12 +67,13 @@ struct Rec {  // pt_bvh.cpp's record: bvh.indices[i] with that object's centre a
     uint32_t idx;
 };
 
-struct BNode {  // 64 B, creation order (level by level)
+struct BNode {  // 88 B, creation order (level by level)
     uint32_t bmin[3], bmax[3];  // Primitive::bounds of the members, as keys
     uint32_t cmin[3], cmax[3];  // bounds of their centres, as keys
     uint32_t first, count;
     uint32_t left;              // id of the left child (right = left + 1); 0 = leaf
     uint32_t slot;              // place in the current level's active list, kNone when the node is finished
+    uint32_t zs[6];             // zero_vote() words of bmin[3], bmax[3]
 };
 
 struct Bins {  // per active node
@@ -82,11 +93,11 @@ struct DBox {
     __device__ void clear() {
         for (int a = 0; a < 3; ++a) { lo[a] = __builtin_inff(); hi[a] = -__builtin_inff(); }
     }
-    __device__ void grow(const DBox& o) {  // AABB::combine; no NaN and no negative zero ever gets here
-        for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], o.lo[a]); hi[a] = fmaxf(hi[a], o.hi[a]); }
+    __device__ void grow(const DBox& o) {  // AABB::combine
+        for (int a = 0; a < 3; ++a) { lo[a] = rmin(lo[a], o.lo[a]); hi[a] = rmax(hi[a], o.hi[a]); }
     }
     __device__ void grow(const float* mn, const float* mx) {
-        for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], mn[a]); hi[a] = fmaxf(hi[a], mx[a]); }
+        for (int a = 0; a < 3; ++a) { lo[a] = rmin(lo[a], mn[a]); hi[a] = rmax(hi[a], mx[a]); }
     }
     __device__ float area() const {  // AABB::area, aabb.rs:42-45
         const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
@@ -103,8 +114,8 @@ __global__ void k_recs_tri(const float* __restrict__ pos, uint32_t n, Rec* rec) 
     Rec r;
     for (int a = 0; a < 3; ++a) {
         r.c[a] = ((p[a] + p[3 + a]) + p[6 + a]) * (1.0f / 3.0f);
-        r.mn[a] = fminf(fminf(p[a], p[3 + a]), p[6 + a]);   // ties between zeros of both signs and NaNs: such inputs are refused (k_root)
-        r.mx[a] = fmaxf(fmaxf(p[a], p[3 + a]), p[6 + a]);
+        r.mn[a] = rmin(rmin(p[a], p[3 + a]), p[6 + a]);
+        r.mx[a] = rmax(rmax(p[a], p[3 + a]), p[6 + a]);
     }
     r.idx = i;
     rec[i] = r;
@@ -124,41 +135,25 @@ __global__ void k_recs_sph(const float* __restrict__ cr, uint32_t n, Rec* rec) {
     rec[i] = r;
 }
 
-// a vertex coordinate that is a negative zero or not finite (the records only hold min / max / sums of them)
-__global__ void k_check_input(const float* __restrict__ v, uint64_t n, uint32_t* unsupported) {
-    bool bad = false;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t u = __float_as_uint(v[i]);
-        bad = bad || u == 0x80000000u || (u & 0x7f800000u) == 0x7f800000u;
-    }
-    if (bad) atomicOr(unsupported, 1u);
-}
-
-// ---- level 0: refuse what the keys cannot order, root bounds
-__global__ void k_root(const Rec* __restrict__ rec, uint32_t n, BNode* nodes, uint32_t* unsupported) {
+// ---- level 0: root bounds (the reference's walk is over the objects in input order)
+__global__ void k_root(const Rec* __restrict__ rec, uint32_t n, BNode* nodes) {
     __shared__ uint32_t acc[12];
     if (threadIdx.x < 12) acc[threadIdx.x] = (threadIdx.x % 6) < 3 ? kKeyPosInf : kKeyNegInf;
     __syncthreads();
-    bool bad = false;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const Rec r = rec[i];
-        for (int k = 0; k < 3; ++k)
-            for (const float f : {r.c[k], r.mn[k], r.mx[k]}) {
-                const uint32_t u = __float_as_uint(f);
-                bad = bad || u == 0x80000000u || (u & 0x7f800000u) == 0x7f800000u;
-            }
         for (int a = 0; a < 3; ++a) {
-            atomicMin(&acc[a], f2key(r.mn[a]));
-            atomicMax(&acc[3 + a], f2key(r.mx[a]));
-            atomicMin(&acc[6 + a], f2key(r.c[a]));
-            atomicMax(&acc[9 + a], f2key(r.c[a]));
+            key_min(&acc[a], r.mn[a]);
+            key_max(&acc[3 + a], r.mx[a]);
+            key_min(&acc[6 + a], r.c[a]);
+            key_max(&acc[9 + a], r.c[a]);
+            zero_vote(&nodes[0].zs[a], r.mn[a], i);
+            zero_vote(&nodes[0].zs[3 + a], r.mx[a], i);
         }
     }
-    if (bad) atomicOr(unsupported, 1u);
     __syncthreads();
     if (threadIdx.x < 12) {
-        uint32_t* dst = threadIdx.x < 3 ? &nodes[0].bmin[threadIdx.x] : threadIdx.x < 6 ? &nodes[0].bmax[threadIdx.x - 3]
-                        : threadIdx.x < 9 ? &nodes[0].cmin[threadIdx.x - 6] : &nodes[0].cmax[threadIdx.x - 9];
+        uint32_t* dst = nodes[0].bmin + threadIdx.x;  // bmin, bmax, cmin, cmax are consecutive
         if ((threadIdx.x % 6) < 3) atomicMin(dst, acc[threadIdx.x]);
         else atomicMax(dst, acc[threadIdx.x]);
     }
@@ -173,6 +168,7 @@ __global__ void k_init_root(BNode* nodes, uint32_t n, uint32_t* seg, uint32_t* a
         r.count = n;
         r.left = 0;
         r.slot = n > 2 ? 0 : kNone;
+        for (int a = 0; a < 6; ++a) r.zs[a] = kNone;
         nodes[0] = r;
         active[0] = 0;
     }
@@ -221,8 +217,8 @@ __global__ void k_bin(const Rec* __restrict__ rec, const uint32_t* __restrict__ 
             const float q = (r.c[a] - lo) / delta;                // bvh.rs:127-132: NaN (0 / 0) -> bin 0
             const int b = a * 8 + (int)fminf(fmaxf(q, 0.0f), 7.0f);
             for (int k = 0; k < 3; ++k) {
-                atomicMin(&B->mn[b][k], f2key(r.mn[k]));
-                atomicMax(&B->mx[b][k], f2key(r.mx[k]));
+                key_min(&B->mn[b][k], r.mn[k]);
+                key_max(&B->mx[b][k], r.mx[k]);
             }
             atomicAdd(&B->n[b], 1u);
         }
@@ -530,6 +526,7 @@ __global__ void k_children(const uint32_t* __restrict__ active, uint32_t n_activ
     const uint32_t pair = atomicAdd(&counters[0], 2u);
     BNode c;
     for (int a = 0; a < 3; ++a) { c.bmin[a] = c.cmin[a] = kKeyPosInf; c.bmax[a] = c.cmax[a] = kKeyNegInf; }
+    for (int a = 0; a < 6; ++a) c.zs[a] = kNone;
     c.left = 0;
     c.first = first;
     c.count = nl;
@@ -598,11 +595,14 @@ __global__ void k_scatter(const Rec* __restrict__ rec, const uint32_t* __restric
                 else rec_next[dest] = r;
                 seg_next[dest] = cs == kSmallSlot ? kNone : cs;
                 uint32_t* b = wave_uniform ? acc[wave] + 12 * right : nodes[sp.pair + right].bmin;  // bmin, bmax, cmin, cmax are consecutive
+                uint32_t* zs = nodes[sp.pair + right].zs;
                 for (int a = 0; a < 3; ++a) {
-                    atomicMin(b + a, f2key(r.mn[a]));
-                    atomicMax(b + 3 + a, f2key(r.mx[a]));
-                    atomicMin(b + 6 + a, f2key(r.c[a]));
-                    atomicMax(b + 9 + a, f2key(r.c[a]));
+                    key_min(b + a, r.mn[a]);
+                    key_max(b + 3 + a, r.mx[a]);
+                    key_min(b + 6 + a, r.c[a]);
+                    key_max(b + 9 + a, r.c[a]);
+                    zero_vote(zs + a, r.mn[a], i);      // i: where the reference's walk over the parent meets this object
+                    zero_vote(zs + 3 + a, r.mx[a], i);
                 }
             }
         }
@@ -657,7 +657,12 @@ __global__ void k_emit(const BNode* __restrict__ nodes, uint32_t n_nodes, const 
     if (v >= n_nodes) return;
     const BNode nd = nodes[v];
     pt_bvh_node o;
-    for (int a = 0; a < 3; ++a) { o.min[a] = key2f(nd.bmin[a]); o.max[a] = key2f(nd.bmax[a]); }
+    for (int a = 0; a < 3; ++a) {
+        o.min[a] = key2f(nd.bmin[a]);
+        o.max[a] = key2f(nd.bmax[a]);
+        if (o.min[a] == 0.0f && nd.zs[a] != kNone && (nd.zs[a] & 1u)) o.min[a] = -0.0f;
+        if (o.max[a] == 0.0f && nd.zs[3 + a] != kNone && (nd.zs[3 + a] & 1u)) o.max[a] = -0.0f;
+    }
     const bool small_split = !nd.left && small_splits[v] != 0;  // split by k_small: its children head its block
     o.left_first = nd.left ? newid[nd.left] : (small_split ? 1 + 2 * event[v] : nd.first);
     o.count = (nd.left || small_split) ? 0u : nd.count;
@@ -788,11 +793,10 @@ void DeviceTree::release() {
     hazard = false;
 }
 
-int build_bvh_device(int prim_kind, const float* d_geom, uint32_t n, DeviceTree& out, hipStream_t st, bool* unsupported, std::string* err) {
-    *unsupported = false;
+int build_bvh_device(int prim_kind, const float* d_geom, uint32_t n, DeviceTree& out, hipStream_t st, std::string* err) {
     out.release();
     if (n == 0 || n > kMaxPrims || !d_geom) return PT_ERR_INVALID;
-    static_assert(sizeof(Rec) == 40 && sizeof(BNode) == 64 && sizeof(Bins) == 672, "layout");
+    static_assert(sizeof(Rec) == 40 && sizeof(BNode) == 88 && sizeof(Bins) == 672, "layout");
 
     const bool dbg = std::getenv("PTCORE_DEBUG") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
@@ -825,22 +829,15 @@ int build_bvh_device(int prim_kind, const float* d_geom, uint32_t n, DeviceTree&
     BUILD_HIP(small_level.alloc((size_t)max_active * 4));
     BUILD_HIP(small_splits.alloc((size_t)max_nodes * 4));
     BUILD_HIP(hipMemsetAsync(small_splits.p, 0, (size_t)max_nodes * 4, st));
-    uint32_t h_cnt[8] = {1, 0, 0, 0, 0, 0, 0, 0};  // nodes, next active, hazard, unsupported, small roots, deepest level below a small root
+    uint32_t h_cnt[8] = {1, 0, 0, 0, 0, 0, 0, 0};  // nodes, next active, hazard, -, small roots, deepest level below a small root
     BUILD_HIP(hipMemcpyAsync(counters.p, h_cnt, 32, hipMemcpyHostToDevice, st));
-    const uint64_t n_floats = (uint64_t)n * (prim_kind == 0 ? 9 : 4);
-    hipLaunchKernelGGL(k_check_input, dim3((uint32_t)std::min<uint64_t>((n_floats + kBlock - 1) / kBlock, 4096)), dim3(kBlock), 0, st, d_geom, n_floats,
-                       counters.as<uint32_t>() + 3);
     if (prim_kind == 0) hipLaunchKernelGGL(k_recs_tri, dim3(blocks(n)), dim3(kBlock), 0, st, d_geom, n, rec_a.as<Rec>());
     else hipLaunchKernelGGL(k_recs_sph, dim3(blocks(n)), dim3(kBlock), 0, st, d_geom, n, rec_a.as<Rec>());
     hipLaunchKernelGGL(k_init_root, dim3(blocks(n)), dim3(kBlock), 0, st, nodes.as<BNode>(), n, seg_a.as<uint32_t>(), act_a.as<uint32_t>());
-    hipLaunchKernelGGL(k_root, dim3(std::min<uint32_t>(blocks(n), 2048)), dim3(kBlock), 0, st, rec_a.as<Rec>(), n, nodes.as<BNode>(), counters.as<uint32_t>() + 3);
+    hipLaunchKernelGGL(k_root, dim3(std::min<uint32_t>(blocks(n), 2048)), dim3(kBlock), 0, st, rec_a.as<Rec>(), n, nodes.as<BNode>());
     BUILD_HIP(hipMemcpyAsync(h_cnt, counters.p, 16, hipMemcpyDeviceToHost, st));
     BUILD_HIP(hipStreamSynchronize(st));
     BUILD_HIP(hipGetLastError());
-    if (h_cnt[3]) {
-        *unsupported = true;
-        return PT_OK;
-    }
     tick("alloc, records, root");
     std::vector<uint32_t> level_start{0, 1};  // node ids of level L are [level_start[L], level_start[L + 1])
     // Subtrees of at most small_limit primitives are finished by one thread each.  Larger is cheaper per primitive (fewer

@@ -110,7 +110,7 @@ def main():
         print(("ok   " if ok else "DIFF ") + "seed %d %s %s" % (seed, name, what), flush=True)
         if not ok:
             sys.exit(1)
-    print("soak: %d rounds (%d trees built on the GPU, the others by the host build), no difference" % (rounds, device_builds))
+    print("soak: %d rounds (%d trees built on the GPU), no difference" % (rounds, device_builds))
 
 
 if __name__ == "__main__":
