@@ -264,7 +264,7 @@ def philox(key, ctr):
 
 
 def math_fn(fn, x, y=None, mode=0):
-    """fn: 0 sin, 1 cos, 2 exp, 3 acos, 4 atan2(x, y)."""
+    """fn: 0 sin, 1 cos, 2 exp, 3 acos, 4 atan2(x, y), 5 cbrt."""
     x = np.ascontiguousarray(x, np.float32)
     y = np.ascontiguousarray(np.zeros_like(x) if y is None else y, np.float32)
     out = np.zeros_like(x)

@@ -84,6 +84,7 @@ struct Math {
     float exp(float x) const { return mode == MATH_DET ? pt_expf(x) : std::exp(x); }
     float acos(float x) const { return mode == MATH_DET ? pt_acosf(x) : std::acos(x); }
     float atan2(float y, float x) const { return mode == MATH_DET ? pt_atan2f(y, x) : std::atan2(y, x); }
+    float cbrt(float x) const { return mode == MATH_DET ? pt_cbrtf(x) : std::cbrt(x); }
 };
 
 // ---------------------------------------------------------------- ray.rs
@@ -343,7 +344,7 @@ struct orc_ctx {
         float cos_theta = -1.0f + (1.0f - -1.0f) * half_open01(r.v[2]);
         float u = 0.0f + (1.0f - 0.0f) * half_open01(r.v[3]);
         float theta = math.acos(cos_theta);
-        float rr = s.radius * std::cbrt(u);
+        float rr = s.radius * math.cbrt(u);
         float st, ct, sp, cp;
         math.sincos(theta, &st, &ct);
         math.sincos(phi, &sp, &cp);
@@ -1013,6 +1014,7 @@ void orc_math(int fn, int mode, const float* x, const float* y, uint64_t n, floa
             case 1: m.sincos(x[i], &s, &c); out[i] = c; break;
             case 2: out[i] = m.exp(x[i]); break;
             case 3: out[i] = m.acos(x[i]); break;
+            case 5: out[i] = m.cbrt(x[i]); break;
             default: out[i] = m.atan2(x[i], y[i]); break;
         }
     }

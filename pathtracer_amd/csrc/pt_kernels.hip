@@ -965,15 +965,13 @@ __device__ __forceinline__ bool shade_core(const DevScene& S, PathVals& pv, cons
                         larea = tri_area(e1, e2);
                     }
                 } else {
-                    // sphere.rs:98-118 (volume sample, x and y both use cos(phi)); cbrt comes from the
-                    // device math library: this sub-case (sphere light seen from speculaty > 1) is
-                    // not covered by the bit-exact guarantee
+                    // sphere.rs:98-118 (volume sample, x and y both use cos(phi))
                     const float4 sp = S.prim[lslot];
                     const float phi = 0.0f + (2.0f * kPi - 0.0f) * half_open01(rn.v[1]);
                     const float cos_theta = -1.0f + (1.0f - -1.0f) * half_open01(rn.v[2]);
                     const float uu = 0.0f + (1.0f - 0.0f) * half_open01(rn.v[3]);
                     const float theta = pt_acosf(cos_theta);
-                    const float rr = sp.w * cbrtf(uu);
+                    const float rr = sp.w * pt_cbrtf(uu);
                     float st, ct, sph, cph;
                     pt_sincosf(theta, &st, &ct);
                     pt_sincosf(phi, &sph, &cph);

@@ -10,6 +10,8 @@ Stated bounds, in units of the last place (ulp) of the reference value:
   pt_expf     <= 2 ulp for x in [-100, 0] (Beer absorption (color - 1) * t <= 0, camera.rs:376-380) and [0, 80]
   pt_acosf    <= 2 ulp on [-1, 1]; NaN outside (scene.rs:164 then reads texel row 0)
   pt_atan2f   <= 4 ulp for finite non-zero inputs; exact C99 results on the axes (scene.rs:163)
+  pt_cbrtf    <= 2 ulp on [0, 1) (u.cbrt() of a uniform sample, sphere.rs:108) and over all finite magnitudes,
+              subnormals included; zeros, infinities and NaN as libm
 (Round 1 shipped pt_sincosf with a wrong Cody-Waite constant: 0.03 rad of error at x = 2 pi, found by this test.)"""
 import numpy as np
 import pytest
@@ -17,7 +19,7 @@ import pytest
 from oracle import orc
 
 f32 = np.float32
-SIN, COS, EXP, ACOS, ATAN2 = 0, 1, 2, 3, 4
+SIN, COS, EXP, ACOS, ATAN2, CBRT = 0, 1, 2, 3, 4, 5
 
 
 def ulps(got, want64):
@@ -92,3 +94,20 @@ def test_atan2(rng):
     got = orc.math_fn(ATAN2, ya, xa, mode=0)
     want = orc.math_fn(ATAN2, ya, xa, mode=1)
     assert got.tobytes() == want.tobytes()
+
+
+def test_cbrt(rng):
+    xs = [rng.random(400_000).astype(f32),                                              # the range the path uses
+          np.exp(rng.uniform(-103.0, 88.0, size=300_000)).astype(f32),                  # every binade, subnormals included
+          np.array([2.0 ** -149, 2.0 ** -127, 2.0 ** -126, 1.0, 8.0, 27.0, 2.0 ** 127, 3.4e38], f32)]
+    for x in xs:
+        x = np.concatenate([x, -x])
+        got = orc.math_fn(CBRT, x, mode=0)
+        libm = orc.math_fn(CBRT, x, mode=1).astype(np.float64)
+        true = np.cbrt(x.astype(np.float64))
+        assert ulps(got, libm).max() <= 2.0
+        assert ulps(got, true).max() <= 2.0
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan], f32)
+    got, want = orc.math_fn(CBRT, special, mode=0), orc.math_fn(CBRT, special, mode=1)
+    assert got[:4].tobytes() == want[:4].tobytes() and np.isnan(got[4])
+    assert orc.math_fn(CBRT, np.array([8.0, 27.0, 1.0, 0.125], f32), mode=0).tolist() == [2.0, 3.0, 1.0, 0.5]

@@ -379,6 +379,28 @@ def test_negative_nee_weight_scene(ptcore, orc, sky):
     g.close()
 
 
+def test_sphere_lights_sampled_bit_exact(ptcore, orc, sky):
+    """Sphere lights seen from a diffuse material with speculaty > 1: the shadow-ray block samples a point INSIDE the
+    light (sphere.rs:98-118, radius * u.cbrt(), x and y both from cos(phi) as written), with cbrt from the shared
+    deterministic math (pt_cbrtf, bounded against libm by tests/test_detmath_cpu.py).  Two lights, so the pick runs too."""
+    cr, mat_id, mats = scenes.default_scene()
+    rows = [scenes.diffuse(1.6, (0.8, 0.7, 0.6)), scenes.emissive(), scenes.GLASS_BLUE]
+    mat_id = np.array([1, 0, 2, 0, 0, 1, 0], np.uint32)
+    scene = (cr, mat_id, scenes.materials(rows))
+    g = ptcore.PathTracer(0).set_scene(scene, sky)
+    o = orc.from_scene(scene, sky)
+    W, H = 72, 48
+    for cam in ((scenes.SPHERE_CAMERA_ORIGIN, scenes.SPHERE_CAMERA_TARGET), ((0.3, 0.6, 1.5), (0.0, -0.4, -2.0))):
+        g.set_camera(*cam, W, H)
+        o.set_camera(*cam, W, H)
+        g.render(3, 32, seed=91)
+        o.render(3, 32, seed=91, nee_mode=0)
+        assert g.read_accum()[0].tobytes() == o.read_accum()[0].tobytes()
+    gc, oc = g.counters(), o.counters()
+    assert gc["rays_any"] == oc["rays_any"] > 1000 and gc["rays_closest"] == oc["rays_closest"]
+    g.close()
+
+
 @pytest.mark.parametrize("name", ["spheres", "cube", "mesh_20k"])
 def test_converged_image_statistical_parity(pairs, name):
     """north_star check 2: equal high spp, independent RNG seeds, libm oracle (the reference's own
