@@ -42,6 +42,11 @@ def draw_scene(rng):
         return "overlap%d" % n, scenes.wrap_mesh(pos, scenes._flat_normals(pos), rng.integers(0, 2, n).astype(np.uint32), rows)
     if kind == 2:
         return "cube", scenes.glass_cube_scene(floor_speculaty=float(rng.choice([0.0, 0.5])), lift=float(rng.choice([0.0, 0.2])))
+    if rng.random() < 0.5:  # random spheres, some of them lights, seen from speculaty > 1 materials: sphere-light NEE (sphere.rs:98-118)
+        n = int(rng.integers(3, 400))
+        cr = np.concatenate([rng.uniform(-1.5, 1.5, size=(n, 3)) * [1, 0.6, 1] + [0, -0.3, -2.0], rng.uniform(0.03, 0.4, size=(n, 1))], axis=1).astype(np.float32)
+        rows = [scenes.diffuse(float(rng.choice([0.0, 0.4, 1.5])), (0.8, 0.7, 0.6)), scenes.emissive(), scenes.GLASS_BLUE, scenes.diffuse(1.3, (0.5, 0.6, 0.9))]
+        return "spheres", (cr, rng.integers(0, 4, n).astype(np.uint32), scenes.materials(rows))
     return "spheres", scenes.default_scene()
 
 
