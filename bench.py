@@ -379,8 +379,8 @@ def main():
             "mpaths_per_s": paths_all / dt_max / 1e6,
             "rays_per_path": rays_all / max(paths_all, 1),
             "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
-            "scene_setup": {"tree_built_on": "gpu" if built_on_device else "host", "tree_ms": tree_ms, "upload_build_flatten_ms": t_build * 1e3,
-                            "note": "outside the timed region: objects + sky uploaded, the reference's BVH built, flattened, primitives put in leaf order"},
+            "scene_setup": {"tree_built_on": "gpu" if built_on_device else "host", "tree_ms": tree_ms, "create_upload_build_ms": t_build * 1e3,
+                            "note": "outside the timed region: pt_create (first HIP call of the process), objects + sky handed over and uploaded, the reference's BVH built, flattened, primitives put in leaf order"},
         }
         if one_gpu:
             out["rehearsal"] = f"{world} ranks on ONE GPU over gloo (collectives staged through the host): a functional check, not a scaling number"
