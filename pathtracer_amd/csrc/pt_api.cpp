@@ -131,7 +131,6 @@ struct pt_ctx {
 
     // host copy of the scene
     int prim_kind = -1;
-    std::vector<float> pos, nrm, cr;
     std::vector<uint32_t> mat_id;
     std::vector<pt_material> mats;
     std::vector<float> sky;
@@ -171,6 +170,9 @@ struct pt_ctx {
     double render_ms = 0;
     uint64_t extend_launches = 0, tail_launches = 0;
     uint64_t opt_batch_slots = 0 /* 0 = the mode's default */, opt_tail_min = kTailMinPaths, opt_tail_fraction = kTailFraction, opt_lanes = 0 /* 0 = the mode's default */, opt_tail_streams = 4, opt_tail_paths_per_lane = 4, opt_first_check = 3, opt_simple_extend = 0, opt_bulk_streams = kMaxLanes, opt_tail_mode = 0, opt_render_mode = 1, opt_merge_calls = kMergeSlots;
+    DevBuf d_raw_a, d_raw_b, d_raw_mat;  // the objects as handed over, on the device: triangles positions + normals (9 floats each),
+                                    // spheres centre + radius; material ids.  The host keeps only the material ids (lights, checks):
+                                    // copying 10 M triangles into host vectors first cost more than building their tree
     DeviceTree dtree;               // the tree of a device build, kept on the GPU until pt_get_bvh asks for it
     bool host_bvh_current = true;   // c->bvh.nodes / indices hold the tree (false: only dtree does)
     uint64_t opt_device_build = 1;  // pt_build builds the tree on the GPU (pt_build.hip) when the input allows it
@@ -293,7 +295,7 @@ void pt_destroy(pt_ctx* c) {
     }
     if (c->acc_stream) (void)hipStreamDestroy(c->acc_stream);
     DevBuf* bufs[] = {&c->d_pairs, &c->d_prim, &c->d_meta, &c->d_nrm, &c->d_big, &c->d_mats, &c->d_sky, &c->d_lights, &c->d_cam,
-                      &c->d_accum, &c->d_rgb, &c->d_stage_in, &c->d_stage_out, &c->d_spill, &c->d_counters};
+                      &c->d_accum, &c->d_rgb, &c->d_raw_a, &c->d_raw_b, &c->d_raw_mat, &c->d_stage_in, &c->d_stage_out, &c->d_spill, &c->d_counters};
     for (DevBuf* b : bufs) b->release();
     if (c->h_rgb) (void)hipHostFree(c->h_rgb);
     c->dtree.release();
@@ -329,11 +331,13 @@ int pt_set_triangles(pt_ctx* c, const float* pos, const float* nrm, const uint32
     if (!pos || !nrm || !mat_id || n == 0) return c->fail(PT_ERR_INVALID, "pt_set_triangles: null input or zero triangles");
     if (int rc = drain(c)) return rc;  // calls in flight still read the old scene
     if (n > kMaxPrims) return c->fail(PT_ERR_LIMIT, "pt_set_triangles: more than 2^26 primitives");
+    PT_HIP(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = dev_upload(c, c->d_raw_a, pos, 9 * n * sizeof(float)))) return rc;
+    if ((rc = dev_upload(c, c->d_raw_b, nrm, 9 * n * sizeof(float)))) return rc;
+    if ((rc = dev_upload(c, c->d_raw_mat, mat_id, n * sizeof(uint32_t)))) return rc;
     c->prim_kind = PRIM_TRIANGLE;
-    c->pos.assign(pos, pos + 9 * n);
-    c->nrm.assign(nrm, nrm + 9 * n);
     c->mat_id.assign(mat_id, mat_id + n);
-    c->cr.clear();
     c->built = false;
     return PT_OK;
 }
@@ -343,11 +347,13 @@ int pt_set_spheres(pt_ctx* c, const float* cr, const uint32_t* mat_id, uint64_t 
     if (!cr || !mat_id || n == 0) return c->fail(PT_ERR_INVALID, "pt_set_spheres: null input or zero spheres");
     if (int rc = drain(c)) return rc;  // calls in flight still read the old scene
     if (n > kMaxPrims) return c->fail(PT_ERR_LIMIT, "pt_set_spheres: more than 2^26 primitives");
+    PT_HIP(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = dev_upload(c, c->d_raw_a, cr, 4 * n * sizeof(float)))) return rc;
+    if ((rc = dev_upload(c, c->d_raw_mat, mat_id, n * sizeof(uint32_t)))) return rc;
+    c->d_raw_b.release();
     c->prim_kind = PRIM_SPHERE;
-    c->cr.assign(cr, cr + 4 * n);
     c->mat_id.assign(mat_id, mat_id + n);
-    c->pos.clear();
-    c->nrm.clear();
     c->built = false;
     return PT_OK;
 }
@@ -370,28 +376,7 @@ int pt_set_sky(pt_ctx* c, const float* rgb, uint32_t w, uint32_t h) {
     return PT_OK;
 }
 
-// the objects as the caller gave them, in device memory for the length of one pt_build / pt_set_bvh
-struct RawGeom {
-    ScopedBuf a, b, mat;  // triangles: positions, normals; spheres: centre + radius, unused; material ids
-    bool uploaded = false;
-};
-
-static int upload_geometry(pt_ctx* c, RawGeom& g) {
-    if (g.uploaded) return PT_OK;
-    const uint64_t n = c->mat_id.size();
-    int rc;
-    if ((rc = dev_upload(c, g.mat, c->mat_id.data(), n * sizeof(uint32_t)))) return rc;
-    if (c->prim_kind == PRIM_TRIANGLE) {
-        if ((rc = dev_upload(c, g.a, c->pos.data(), 9 * n * sizeof(float)))) return rc;
-        if ((rc = dev_upload(c, g.b, c->nrm.data(), 9 * n * sizeof(float)))) return rc;
-    } else {
-        if ((rc = dev_upload(c, g.a, c->cr.data(), 4 * n * sizeof(float)))) return rc;
-    }
-    g.uploaded = true;
-    return PT_OK;
-}
-
-static int finalize_scene(pt_ctx* c, RawGeom& raw);
+static int finalize_scene(pt_ctx* c);
 
 int pt_build(pt_ctx* c) {
     if (!c) return PT_ERR_INVALID;
@@ -404,17 +389,13 @@ int pt_build(pt_ctx* c) {
         if (dbg) std::fprintf(stderr, "[ptcore] pt_build: %-24s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - since).count());
     };
     PT_HIP(c, hipSetDevice(c->device));
-    RawGeom raw;
     c->dtree.release();
     c->build_on_device = false;
     c->built = false;
     if (c->opt_device_build) {  // same tree either way
-        const auto t_up = std::chrono::steady_clock::now();
-        if (int rc = upload_geometry(c, raw)) return rc;
-        tick("upload objects", t_up);
         const auto t0 = std::chrono::steady_clock::now();
         std::string why;
-        if (int rc = build_bvh_device(c->prim_kind == PRIM_TRIANGLE ? 0 : 1, (const float*)raw.a.p, (uint32_t)n, c->dtree, c->stream, &why))
+        if (int rc = build_bvh_device(c->prim_kind == PRIM_TRIANGLE ? 0 : 1, (const float*)c->d_raw_a.p, (uint32_t)n, c->dtree, c->stream, &why))
             return c->fail(rc, why);
         c->build_on_device = true;
         c->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -428,8 +409,13 @@ int pt_build(pt_ctx* c) {
     if (!c->build_on_device) {
         const auto t0 = std::chrono::steady_clock::now();
         std::vector<PrimInfo> info;
-        if (c->prim_kind == PRIM_TRIANGLE) prim_info_triangles(c->pos.data(), n, info);
-        else prim_info_spheres(c->cr.data(), n, info);
+        {   // the host build reads the objects back (they live on the device only)
+            const size_t per = c->prim_kind == PRIM_TRIANGLE ? 9 : 4;
+            std::vector<float> geom(per * n);
+            PT_HIP(c, hipMemcpy(geom.data(), c->d_raw_a.p, geom.size() * sizeof(float), hipMemcpyDeviceToHost));
+            if (c->prim_kind == PRIM_TRIANGLE) prim_info_triangles(geom.data(), n, info);
+            else prim_info_spheres(geom.data(), n, info);
+        }
         build_bvh(info, c->bvh);
         c->host_bvh_current = true;
         c->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -437,7 +423,7 @@ int pt_build(pt_ctx* c) {
     }
     if (c->bvh.hazard) return c->fail(PT_ERR_BVH, "pt_build: a partition produced an empty child");
     const auto t_fin = std::chrono::steady_clock::now();
-    const int rc = finalize_scene(c, raw);
+    const int rc = finalize_scene(c);
     tick("flatten, reorder, upload", t_fin);
     return rc;
 }
@@ -492,8 +478,7 @@ int pt_set_bvh(pt_ctx* c, const pt_bvh_node* nodes, uint64_t n_nodes, const uint
     c->host_bvh_current = true;
     c->build_on_device = false;
     c->build_ms = 0;
-    RawGeom raw;
-    return finalize_scene(c, raw);
+    return finalize_scene(c);
 }
 
 int pt_bvh_build(int prim_kind, const float* geom, uint64_t n, pt_bvh_node* nodes, uint64_t nodes_cap, uint64_t* indices,
@@ -516,7 +501,7 @@ int pt_bvh_build(int prim_kind, const float* geom, uint64_t n, pt_bvh_node* node
     return PT_OK;
 }
 
-static int finalize_scene(pt_ctx* c, RawGeom& raw) {
+static int finalize_scene(pt_ctx* c) {
     PT_HIP(c, hipSetDevice(c->device));
     const uint64_t n = c->mat_id.size();
     const bool dbg = std::getenv("PTCORE_DEBUG") != nullptr;
@@ -574,7 +559,6 @@ static int finalize_scene(pt_ctx* c, RawGeom& raw) {
     {
         ScopedBuf raw_idx, d_slot;
         const uint32_t n32 = (uint32_t)n;
-        if ((rc = upload_geometry(c, raw))) return rc;
         const uint32_t* d_idx = c->dtree.indices;
         if (!on_device) {
             if ((rc = dev_upload(c, raw_idx, c->bvh.indices.data(), n * sizeof(uint32_t)))) return rc;
@@ -585,13 +569,13 @@ static int finalize_scene(pt_ctx* c, RawGeom& raw) {
             if ((rc = dev_alloc(c, c->d_prim, 4 * (size_t)kTriStride * n * sizeof(float)))) return rc;
             if ((rc = dev_alloc(c, c->d_nrm, (size_t)kNrmStride * n * sizeof(float)))) return rc;
             if ((rc = dev_alloc(c, c->d_meta, 16))) return rc;
-            launch_reorder_triangles((const float*)raw.a.p, (const float*)raw.b.p, (const uint32_t*)raw.mat.p, d_idx, n32, (float*)c->d_prim.p,
+            launch_reorder_triangles((const float*)c->d_raw_a.p, (const float*)c->d_raw_b.p, (const uint32_t*)c->d_raw_mat.p, d_idx, n32, (float*)c->d_prim.p,
                                      (float*)c->d_nrm.p, (uint32_t*)d_slot.p, c->stream);
         } else {
             if ((rc = dev_alloc(c, c->d_prim, 4 * n * sizeof(float)))) return rc;
             if ((rc = dev_alloc(c, c->d_meta, 2 * n * sizeof(uint32_t)))) return rc;
             if ((rc = dev_alloc(c, c->d_nrm, 16))) return rc;
-            launch_reorder_spheres((const float*)raw.a.p, (const uint32_t*)raw.mat.p, d_idx, n32, (float*)c->d_prim.p, (uint32_t*)c->d_meta.p,
+            launch_reorder_spheres((const float*)c->d_raw_a.p, (const uint32_t*)c->d_raw_mat.p, d_idx, n32, (float*)c->d_prim.p, (uint32_t*)c->d_meta.p,
                                    (uint32_t*)d_slot.p, c->stream);
         }
         PT_HIP(c, hipGetLastError());
