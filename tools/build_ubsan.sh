@@ -9,6 +9,7 @@ F="--offload-arch=gfx950 -O1 -g -std=c++17 -ffp-contract=off -fno-fast-math -fPI
 hipcc $F -x hip -c pt_api.cpp -o $out/obj_ubsan/pt_api.o &
 hipcc $F -x hip -c pt_bvh.cpp -o $out/obj_ubsan/pt_bvh.o &
 hipcc $F -c pt_kernels.hip -o $out/obj_ubsan/pt_kernels.o &
+hipcc $F -c pt_build.hip -o $out/obj_ubsan/pt_build.o &
 wait
 D=$(ls -d /opt/rocm/lib/llvm/lib/clang/*/lib/linux)
 hipcc --offload-arch=gfx950 -shared -fPIC -o $out/libptcore_ubsan.so $out/obj_ubsan/*.o -Wl,--whole-archive \
