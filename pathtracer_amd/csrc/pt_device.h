@@ -199,16 +199,26 @@ PT_DEV uint8_t tonemap_channel(float c) {
     return (uint8_t)v;
 }
 
+// n / d for n < 2^31 (pt_pixelmap.h)
+PT_DEV uint32_t fastdiv(uint32_t n, FastDiv f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return f.m ? (__umulhi(n, f.m) >> f.sh) : n;
+#else
+    return f.m ? (uint32_t)(((uint64_t)n * f.m) >> 32) >> f.sh : n;
+#endif
+}
+
 // slot index inside one sample -> pixel
 PT_DEV bool map_pixel(const PixelMap& M, uint32_t idx, uint32_t* x_out, uint32_t* y_out) {
     const uint32_t per_tile = M.tile * M.tile;
-    const uint32_t local_tile = idx / per_tile, within = idx % per_tile;
+    const uint32_t local_tile = fastdiv(idx, M.fd_per_tile), within = idx - local_tile * per_tile;
     const uint32_t T = local_tile * M.nranks + M.rank;
-    const uint32_t tx = T % M.tiles_x, ty = T / M.tiles_x;
+    const uint32_t ty = fastdiv(T, M.fd_tiles_x), tx = T - ty * M.tiles_x;
     const uint32_t sub = within >> 6, lane = within & 63u;
     const uint32_t subs = M.tile >> 3;
-    const uint32_t x = tx * M.tile + (sub % subs) * 8 + (lane & 7u);
-    const uint32_t y = ty * M.tile + (sub / subs) * 8 + (lane >> 3);
+    const uint32_t sy = fastdiv(sub, M.fd_subs), sx = sub - sy * subs;
+    const uint32_t x = tx * M.tile + sx * 8 + (lane & 7u);
+    const uint32_t y = ty * M.tile + sy * 8 + (lane >> 3);
     *x_out = x;
     *y_out = y;
     return x < M.width && y < M.height;

@@ -1290,7 +1290,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_tail_pw(DevScene S, PathState P
 // slots are pixel-major (8x8-tile pixel order, then the samples of the pixel), and every value is
 // computed by the same device functions, so the sums are bit-identical.
 template <int PRIM, bool NEE, bool COUNT>
-__global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, const DevCamera* __restrict__ camp, PixelMap M, uint32_t n_samples,
+__global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, const DevCamera* __restrict__ camp, PixelMap M, uint32_t n_samples, FastDiv fd_samples,
                                                       uint32_t sample_base, uint32_t depth, uint32_t k0, uint32_t k1,
                                                       float4* __restrict__ out, uint32_t* __restrict__ cursor, LaunchCfg cfg,
                                                       unsigned long long* counters) {
@@ -1338,7 +1338,7 @@ __global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, c
                 pv.o = T.o;
                 pv.d = T.d;
                 {   // the RNG counter words (pixel, sample) follow from the slot: not kept across the traversal loop
-                    const uint32_t pix_idx = T.slot / n_samples;
+                    const uint32_t pix_idx = fastdiv(T.slot, fd_samples);
                     uint32_t x, y;
                     map_pixel(M, pix_idx, &x, &y);
                     pv.pixel = y * M.width + x;
@@ -1368,7 +1368,7 @@ __global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, c
                 if (idx < chunk_end) {
                     // pixel-major slots: the samples of a pixel are neighbours, so the lanes of a wave start
                     // with (nearly) the same primary ray and walk the same nodes
-                    const uint32_t pix_idx = idx / n_samples, s_local = idx - pix_idx * n_samples;
+                    const uint32_t pix_idx = fastdiv(idx, fd_samples), s_local = idx - pix_idx * n_samples;
                     uint32_t x, y;
                     if (map_pixel(M, pix_idx, &x, &y)) {
                         T.slot = idx;
@@ -1623,7 +1623,7 @@ void launch_path(int prim, bool nee, bool count, const DevScene& S, const DevCam
                  unsigned long long* counters, hipStream_t st) {
     const uint64_t total = (uint64_t)n_samples * M.npix_pad;
     const uint32_t grid = blocks_for(total, kTraceBlock, cfg.grid);
-#define PT_PATH(PR, N, C) hipLaunchKernelGGL((k_path<PR, N, C>), dim3(grid), dim3(kTraceBlock), 0, st, S, cam, M, n_samples, sample_base, depth, k0, k1, out, cursor, cfg, counters)
+#define PT_PATH(PR, N, C) hipLaunchKernelGGL((k_path<PR, N, C>), dim3(grid), dim3(kTraceBlock), 0, st, S, cam, M, n_samples, fastdiv_make(n_samples), sample_base, depth, k0, k1, out, cursor, cfg, counters)
     if (prim == PRIM_TRIANGLE) {
         if (nee) { if (count) PT_PATH(PRIM_TRIANGLE, true, true); else PT_PATH(PRIM_TRIANGLE, true, false); }
         else { if (count) PT_PATH(PRIM_TRIANGLE, false, true); else PT_PATH(PRIM_TRIANGLE, false, false); }

@@ -58,3 +58,40 @@ def test_product_does_not_reference_oracle():
                 if re.search(r"oracle[/.]|liborc|from oracle|import oracle", txt):
                     bad.append(os.path.join(base, f))
     assert not bad, bad
+
+
+def test_fastdiv_is_exact(tmp_path):
+    """pt_pixelmap.h FastDiv: floor(n / d) for n < 2^31 as multiply-high + shift (the slot -> pixel mapping of the kernels
+    and of pt_shard_map).  Every d up to 5000, powers of two and their neighbours, random d; n at 0, around multiples
+    of d, at 2^31 - 1 and random."""
+    import os
+    import subprocess
+    src = tmp_path / "fd.cpp"
+    src.write_text(r'''
+#include "pt_pixelmap.h"
+#include <cstdio>
+#include <random>
+using namespace pt;
+static uint32_t fd(uint32_t n, FastDiv f) { return f.m ? (uint32_t)(((uint64_t)n * f.m) >> 32) >> f.sh : n; }
+int main() {
+    std::mt19937_64 rng(1);
+    unsigned long long bad = 0, checked = 0;
+    auto check = [&](uint32_t d) {
+        FastDiv f = fastdiv_make(d);
+        uint32_t ns[] = {0, 1, d - 1, d, d + 1, 2 * d - 1, 2 * d, 0x7fffffffu, 0x7ffffffeu, 0x7fffffffu / d * d, 0x7fffffffu / d * d - 1};
+        for (uint32_t n : ns) if (n < 0x80000000u) { bad += fd(n, f) != n / d; ++checked; }
+        for (int k = 0; k < 300; ++k) { uint32_t n = (uint32_t)(rng() & 0x7fffffffu); bad += fd(n, f) != n / d; ++checked; }
+        for (int q = 0; q < 100; ++q) { uint64_t n = (uint64_t)(rng() % (0x80000000ull / d + 1)) * d; for (int o = -1; o <= 1; ++o) { uint64_t m = n + o; if (m < 0x80000000ull) { bad += fd((uint32_t)m, f) != (uint32_t)m / d; ++checked; } } }
+    };
+    for (uint32_t d = 1; d <= 5000; ++d) check(d);
+    for (int k = 0; k < 20000; ++k) check((uint32_t)(rng() % 0x7fffffffu) + 1);
+    for (int l = 0; l < 31; ++l) { check(1u << l); check((1u << l) + 1); if (l) check((1u << l) - 1); }
+    std::printf("%llu %llu\n", checked, bad);
+    return bad != 0;
+}
+''')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "fd")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(root, "pathtracer_amd", "csrc"), str(src), "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.split()[1] == "0", r.stdout
