@@ -451,7 +451,7 @@ struct LaneTrav {
     V3 o, d, rcp;
     float dist;
     uint32_t cur, sp;
-    uint32_t hslot, hinside;
+    uint32_t hslot;   // winning primitive slot | Intersection::inside << 31 (slots have 26 bits), PT_MISS if none
     float hu, hv;
     uint32_t slot;  // path slot the ray belongs to
 };
@@ -510,7 +510,6 @@ __device__ __forceinline__ bool lane_start_ray(const DevScene& S, LaneTrav& T, f
     T.rcp = V3{1.0f / T.d.x, 1.0f / T.d.y, 1.0f / T.d.z};
     T.dist = ro.w;
     T.hslot = PT_MISS;
-    T.hinside = 0;
     T.hu = T.hv = 0.f;
     T.sp = 0;
     float tmin;
@@ -585,10 +584,9 @@ __device__ __forceinline__ void test_prim(const DevScene& S, LaneTrav& T, uint32
         float t, u, v, det;
         if (tri_hit(V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, V3{b.z, b.w, c.x}, T.o, T.d, &t, &u, &v, &det)) {
             T.dist = t;  // unconditionally, triangle.rs:72
-            T.hslot = ps;
+            T.hslot = ps | (det < 0.0f ? 0x80000000u : 0u);
             T.hu = u;
             T.hv = v;
-            T.hinside = det < 0.0f ? 1u : 0u;
         }
     } else {
         const float4 sp4 = S.prim[ps];
@@ -596,8 +594,7 @@ __device__ __forceinline__ void test_prim(const DevScene& S, LaneTrav& T, uint32
         bool inside;
         if (sphere_hit(V3{sp4.x, sp4.y, sp4.z}, sp4.w, T.o, T.d, T.dist, &t, &inside)) {
             T.dist = t;
-            T.hslot = ps;
-            T.hinside = inside ? 1u : 0u;
+            T.hslot = ps | (inside ? 0x80000000u : 0u);
         }
     }
 }
@@ -701,10 +698,9 @@ __device__ __forceinline__ void step_prim_wave(const DevScene& S, LaneTrav& T, b
             if (COUNT) np += n;
             if (win != PT_MISS) {
                 T.dist = wt;  // unconditionally, triangle.rs:72
-                T.hslot = win;
+                T.hslot = win | (wdet < 0.0f ? 0x80000000u : 0u);
                 T.hu = wu;
                 T.hv = wv;
-                T.hinside = wdet < 0.0f ? 1u : 0u;
             }
             if (!lane_pop(T, stk)) active = false;
         }
@@ -732,7 +728,7 @@ __device__ __forceinline__ void wave_step(const DevScene& S, LaneTrav& T, bool& 
 }
 
 __device__ __forceinline__ void lane_store_hit(const PathState& P, const LaneTrav& T) {
-    const uint32_t bits = T.hslot == PT_MISS ? PT_MISS : (T.hslot | (T.hinside << 31));
+    const uint32_t bits = T.hslot;
     P.hit[T.slot] = make_float4(__uint_as_float(bits), T.dist, T.hu, T.hv);
 }
 
@@ -798,7 +794,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_extend_pw(DevScene S, PathState
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t nn = 0, np = 0, worst = 0, mine = 0;
     LaneTrav T;
-    T.cur = 0; T.sp = 0; T.dist = 0.f; T.hslot = PT_MISS; T.hinside = 0; T.hu = T.hv = 0.f; T.slot = 0;
+    T.cur = 0; T.sp = 0; T.dist = 0.f; T.hslot = PT_MISS; T.hu = T.hv = 0.f; T.slot = 0;
     T.o = T.d = T.rcp = V3{0.f, 0.f, 0.f};
     bool active = false;
     bool drained = false;  // wave-uniform: the queue has no more rays for this wave
@@ -1210,7 +1206,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_tail_pw(DevScene S, PathState P
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t nn = 0, np = 0, worst = 0, mine = 0, rays = 0;
     LaneTrav T;
-    T.cur = 0; T.sp = 0; T.dist = 0.f; T.hslot = PT_MISS; T.hinside = 0; T.hu = T.hv = 0.f; T.slot = 0;
+    T.cur = 0; T.sp = 0; T.dist = 0.f; T.hslot = PT_MISS; T.hu = T.hv = 0.f; T.slot = 0;
     T.o = T.d = T.rcp = V3{0.f, 0.f, 0.f};
     bool active = false;   // traversing
     bool pending = false;  // traversal finished, hit record stored, waits for shade_one
@@ -1302,7 +1298,7 @@ __global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, c
     uint32_t nn = 0, np = 0, worst = 0, mine = 0;
     uint32_t rays = 0, paths = 0;  // wave-uniform tallies (scalar registers)
     LaneTrav T;
-    T.cur = 0; T.sp = 0; T.dist = 0.f; T.hslot = PT_MISS; T.hinside = 0; T.hu = T.hv = 0.f; T.slot = 0;
+    T.cur = 0; T.sp = 0; T.dist = 0.f; T.hslot = PT_MISS; T.hu = T.hv = 0.f; T.slot = 0;
     T.o = T.d = T.rcp = V3{0.f, 0.f, 0.f};
     PathVals pv;
     pv.o = pv.d = pv.transport = pv.acc = V3{0.f, 0.f, 0.f};
@@ -1331,7 +1327,7 @@ __global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, c
             if (pending) {
                 pending = false;
                 HitVals hv;
-                hv.bits = T.hslot == PT_MISS ? PT_MISS : (T.hslot | (T.hinside << 31));
+                hv.bits = T.hslot;
                 hv.t = T.dist;
                 hv.u = T.hu;
                 hv.v = T.hv;
