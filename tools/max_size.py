@@ -1,0 +1,94 @@
+"""The documented maximum, 2^26 primitives, end to end: python tools/max_size.py [log2_n=26] [oracle=1]
+
+A triangle soup of exactly 2^n triangles (light and floor included): tree built on the GPU against the threaded host
+build and against the oracle's scalar build (same nodes, same index order), 2 M rays through the GPU and 100 k of them
+through the oracle (same hits), one small frame rendered.  A tool, not a suite test: the scene alone takes minutes to
+generate and the oracle's build as long again."""
+import sys
+import threading
+import time
+
+import numpy as np
+
+sys.path.insert(0, '.')
+import torch  # noqa: F401,E402
+from pathtracer_amd import ptcore, scenes  # noqa: E402
+from oracle import orc  # noqa: E402
+
+log2_n = int(sys.argv[1]) if len(sys.argv) > 1 else 26
+with_oracle = (sys.argv[2] != "0") if len(sys.argv) > 2 else True
+T0 = time.time()
+
+
+def say(*a):
+    print(f"[{time.time() - T0:7.1f} s]", *a, flush=True)
+
+
+alive = True
+
+
+def heartbeat():
+    while alive:
+        time.sleep(45)
+        if alive:
+            say("...")
+
+
+threading.Thread(target=heartbeat, daemon=True).start()
+
+n = (1 << log2_n) - 3
+scene = scenes.soup_scene(n=n, seed=11)
+pos, nrm, mat, mats = scene
+say(f"{len(pos)} triangles generated ({pos.nbytes / 2**30:.1f} GiB of positions)")
+assert len(pos) == 1 << log2_n
+
+sky = scenes.make_sky()
+g = ptcore.PathTracer(0)
+g.set_materials(mats)
+g.set_triangles(pos, nrm, mat)
+g.set_sky(sky)
+trees = {}
+for on in (1, 0):
+    g.set_option(ptcore.OPT_DEVICE_BUILD, on)
+    t0 = time.time()
+    g.build()
+    wall = time.time() - t0
+    dev, ms = g.build_info()
+    nodes, idx, depth = g.bvh()
+    trees[on] = (nodes.copy(), idx.copy(), depth)
+    say(f"{'device' if dev else 'host  '} build: tree {ms:9.1f} ms, pt_build in all {wall * 1e3:9.1f} ms, {len(nodes)} nodes, depth {depth}")
+same = trees[1][2] == trees[0][2] and np.array_equal(trees[1][1], trees[0][1]) and trees[1][0].tobytes() == trees[0][0].tobytes()
+say("device tree == host tree:", same)
+ok = same
+
+g.set_option(ptcore.OPT_DEVICE_BUILD, 1)
+g.build()
+rays = scenes.random_rays(2_000_000, seed=3, aim=(0.0, 0.7, 0.0), aim_sigma=1.0)
+t0 = time.time()
+hits = g.trace(rays)
+say(f"2 M rays traced in {time.time() - t0:.2f} s (host buffers), {int((hits['prim'] != ptcore.MISS).sum())} hit")
+g.set_camera((0.0, 1.0, 3.5), (0.0, 0.6, 0.0), 256, 256)
+g.render(4, 8, seed=1)
+acc, spp = g.read_accum()
+say(f"256 x 256 frame, {spp} spp: mean {float(np.nanmean(acc)):.4f}, finite {bool(np.isfinite(acc).all())}")
+
+if with_oracle:
+    o = orc.Oracle()
+    o.set_materials(mats)
+    o.set_triangles(pos, nrm, mat)
+    o.set_sky(sky)
+    t0 = time.time()
+    o.build()
+    onodes, oidx, odepth = o.bvh()
+    say(f"oracle build {time.time() - t0:.1f} s, {len(onodes)} nodes, depth {odepth}")
+    same_o = odepth == trees[1][2] and np.array_equal(oidx, trees[1][1]) and np.asarray(onodes).tobytes() == trees[1][0].tobytes()
+    say("device tree == oracle tree:", same_o)
+    sub = rays[:100_000]
+    oh = o.trace(sub)
+    gh = g.trace(sub)
+    same_h = np.asarray(oh).tobytes() == np.asarray(gh).tobytes()
+    say("100 k rays, GPU hits == oracle hits:", same_h)
+    ok = ok and same_o and same_h
+alive = False
+say("OK" if ok else "MISMATCH")
+sys.exit(0 if ok else 1)
