@@ -254,7 +254,7 @@ int pt_create(int device, pt_ctx** out) {
             }
     }
     if (resolve_scratch(device, &c->scratch_ptr) != hipSuccess) {  // hipSetDevice(device) happened above
-        delete c;
+        pt_destroy(c);
         return PT_ERR_HIP;
     }
     c->sched = new pt_sched();
