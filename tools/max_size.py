@@ -1,4 +1,4 @@
-"""The documented maximum, 2^26 primitives, end to end: python tools/max_size.py [log2_n=26] [oracle=1]
+"""The documented maximum, 2^26 primitives, end to end: python tools/max_size.py [log2_n=26] [oracle=1] [triangles|spheres]
 
 A triangle soup of exactly 2^n triangles (light and floor included): tree built on the GPU against the threaded host
 build and against the oracle's scalar build (same nodes, same index order), 2 M rays through the GPU and 100 k of them
@@ -17,6 +17,7 @@ from oracle import orc  # noqa: E402
 
 log2_n = int(sys.argv[1]) if len(sys.argv) > 1 else 26
 with_oracle = (sys.argv[2] != "0") if len(sys.argv) > 2 else True
+spheres = len(sys.argv) > 3 and sys.argv[3] == "spheres"
 T0 = time.time()
 
 
@@ -36,16 +37,29 @@ def heartbeat():
 
 threading.Thread(target=heartbeat, daemon=True).start()
 
-n = (1 << log2_n) - 3
-scene = scenes.soup_scene(n=n, seed=11)
-pos, nrm, mat, mats = scene
-say(f"{len(pos)} triangles generated ({pos.nbytes / 2**30:.1f} GiB of positions)")
+if spheres:  # small spheres all over the soup's box, the sphere scene's materials (every seventh sphere a light)
+    rng = np.random.default_rng(11)
+    n = 1 << log2_n
+    pos = np.empty((n, 4), np.float32)
+    pos[:, :3] = rng.uniform([-2, -0.3, -2], [2, 1.7, 2], size=(n, 3))
+    pos[:, 3] = rng.uniform(0.0005, 0.004, size=n)
+    mats = scenes.default_scene()[2]
+    mat = (np.arange(n) % len(mats)).astype(np.uint32)
+    nrm = None
+    say(f"{n} spheres generated")
+else:
+    n = (1 << log2_n) - 3
+    pos, nrm, mat, mats = scenes.soup_scene(n=n, seed=11)
+    say(f"{len(pos)} triangles generated ({pos.nbytes / 2**30:.1f} GiB of positions)")
 assert len(pos) == 1 << log2_n
 
 sky = scenes.make_sky()
 g = ptcore.PathTracer(0)
 g.set_materials(mats)
-g.set_triangles(pos, nrm, mat)
+if spheres:
+    g.set_spheres(pos, mat)
+else:
+    g.set_triangles(pos, nrm, mat)
 g.set_sky(sky)
 trees = {}
 for on in (1, 0):
@@ -75,7 +89,10 @@ say(f"256 x 256 frame, {spp} spp: mean {float(np.nanmean(acc)):.4f}, finite {boo
 if with_oracle:
     o = orc.Oracle()
     o.set_materials(mats)
-    o.set_triangles(pos, nrm, mat)
+    if spheres:
+        o.set_spheres(pos, mat)
+    else:
+        o.set_triangles(pos, nrm, mat)
     o.set_sky(sky)
     t0 = time.time()
     o.build()
