@@ -428,6 +428,66 @@ def test_converged_image_statistical_parity(pairs, name):
     assert (rel < 0.01).all(), rel
 
 
+def test_documented_limits_of_materials_and_depth(ptcore, orc, sky):
+    """32 768 materials (the id rides in 15 bits across a look-ahead) and max_depth 65 535 (the
+    iteration counter has 16 bits), both AT the limit against the oracle and one past it refused.  Materials: 40 000
+    triangles using every id, glass, light and a speculaty > 1 row at the top ids.  Depth: the camera inside a closed box
+    of perfect mirrors, so every path that does not slip out through an edge really takes 65 535 bounces."""
+    rng = np.random.default_rng(41)
+    n_mat = 1 << 15
+    rows = [scenes.diffuse(float(rng.choice([0.0, 0.5])), tuple(rng.uniform(0.2, 0.9, size=3))) for _ in range(n_mat)]
+    rows[n_mat - 1] = scenes.dielectric(1.0, 1.5, (0.6, 0.9, 0.7))
+    rows[n_mat - 2] = scenes.emissive()
+    rows[n_mat - 3] = scenes.diffuse(1.5, (0.8, 0.7, 0.6))
+    pos, nrm, _, _ = scenes.soup_scene(40000 - 3, 8)
+    ids = (np.arange(len(pos)) % n_mat).astype(np.uint32)
+    ids[::5] = n_mat - 1 - (np.arange(len(ids[::5])) % 3)     # plenty of glass, lights and shadow-ray surfaces
+    scene = (pos, nrm, ids, scenes.materials(rows))
+    g = ptcore.PathTracer(0).set_scene(scene, sky)
+    o = orc.from_scene(scene, sky)
+    W, H = 48, 32
+    cam = ((-1.6, 0.9, -1.3), (0.0, 0.6, 0.0))
+    g.set_camera(*cam, W, H)
+    o.set_camera(*cam, W, H)
+    o.render(2, 16, seed=13, nee_mode=0)
+    want = o.read_accum()[0]
+    for mode in (1, 0):
+        g.set_option(ptcore.OPT_RENDER_MODE, mode)
+        g.reset_accum()
+        g.render(2, 16, seed=13)
+        assert g.read_accum()[0].tobytes() == want.tobytes(), mode
+    assert g.counters()["rays_any"] > 0
+    with pytest.raises(ptcore.PtError) as e:
+        g.set_materials(scenes.materials(rows + [scenes.emissive()]))
+    assert e.value.status == ptcore.PT_ERR_LIMIT
+    g.close()
+
+    box, box_n = scenes.cube_mesh(centre_xz=(0.0, 0.0), side=2.0, base_y=-1.0)
+    box = np.ascontiguousarray(box.reshape(-1, 3, 3)[:, [0, 2, 1]].reshape(-1, 9))  # wound to face inward: a diffuse hit from
+    box_n = np.ascontiguousarray(-box_n)                                             # behind ends the path (camera.rs:313)
+    scene = (box, box_n, np.zeros(len(box), np.uint32), scenes.materials([scenes.diffuse(1.0, (1.0, 1.0, 1.0))]))
+    g = ptcore.PathTracer(0).set_scene(scene, sky)
+    o = orc.from_scene(scene, sky)
+    cam = ((0.1, 0.2, 0.3), (1.0, 0.3, 0.5))
+    g.set_camera(*cam, 8, 8)
+    o.set_camera(*cam, 8, 8)
+    o.reset_counters()
+    o.render(1, 65535, seed=3, nee_mode=1)
+    want = o.read_accum()[0]
+    assert o.counters()["rays_closest"] > 60 * 65535       # nearly every path went all the way
+    for mode in (1, 0):
+        g.set_option(ptcore.OPT_RENDER_MODE, mode)
+        g.reset_accum()
+        g.reset_counters()
+        g.render(1, 65535, seed=3)
+        assert g.read_accum()[0].tobytes() == want.tobytes(), mode
+        assert g.counters()["rays_closest"] == o.counters()["rays_closest"], mode
+    with pytest.raises(ptcore.PtError) as e:
+        g.render(1, 65536, seed=3)
+    assert e.value.status == ptcore.PT_ERR_LIMIT
+    g.close()
+
+
 def test_error_paths(ptcore, sky):
     g = ptcore.PathTracer(0)
     with pytest.raises(ptcore.PtError) as e:
