@@ -41,8 +41,13 @@ namespace pt {
 namespace {
 
 constexpr uint32_t kNone = 0xffffffffu;
-constexpr uint32_t kSmallSlot = 0xfffffffeu;  // "slot" of a node that one thread will finish on its own (k_small)
-constexpr uint32_t kSmall = 128;              // ... nodes of at most this many primitives (the limit of a build is chosen from n, see small_limit)
+constexpr uint32_t kSmallSlot = 0xfffffffeu;  // "slot" of a node that one wave will finish on its own (k_small_wave)
+#ifndef PT_BUILD_SMALL
+#define PT_BUILD_SMALL 128
+#endif
+constexpr uint32_t kSmall = PT_BUILD_SMALL;      // ... nodes of at most this many primitives
+constexpr int kSmallPerLane = kSmall / 64;    // k_small_wave: primitives of a node per lane
+static_assert(kSmall % 64 == 0, "k_small_wave handles whole waves of primitives");
 constexpr uint32_t kKeyPosInf = 0xff800000u;  // key(+inf): identity of min
 constexpr uint32_t kKeyNegInf = 0x007fffffu;  // key(-inf): identity of max
 constexpr int kBlock = 256;
@@ -293,112 +298,199 @@ __global__ void k_sah(const uint32_t* __restrict__ active, uint32_t n_active, co
     split[s] = sp;
 }
 
-// ---- one thread finishes the subtree of a node of at most kSmall primitives, depth first as the reference does
-// (bvh.rs:52-103 with its explicit stack and its swap walk; the records of the node are the thread's own).  Its nodes
-// go to a private block — the children of the subtree's k-th split at block places 2k and 2k + 1, which is the
-// reference's numbering relative to the block — and k_emit_small moves the block to its place once the split event
-// of the subtree's root is known.
-__global__ void k_small(const uint32_t* __restrict__ small_list, const uint32_t* __restrict__ small_level, uint32_t n_small, const BNode* __restrict__ nodes,
-                        Rec* small_rec, pt_bvh_node* small_nodes, uint32_t* small_splits, uint32_t* final_idx, uint32_t* counters) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_small) return;
+// ---- one WAVE finishes the subtree of a node of at most kSmall primitives, depth first as the reference does
+// (bvh.rs:52-103 with its explicit stack).  The subtree's records live in LDS; every phase of a node (centre bounds,
+// bins, flags, places, child bounds) runs over its primitives two per lane, the sweep on three lanes (one per axis,
+// combined in axis order with the sweep's own strict <), and the order inside the two halves comes from the flags by
+// the rule of k_lpos / k_scatter.  Bounds are reduced as keys with zero votes (position in the node = the order in
+// which the reference's walk meets the objects), exactly as for the large nodes.  The subtree's nodes go to a private
+// block — the children of its k-th split at block places 2k and 2k + 1, which is the reference's numbering relative
+// to the block — and k_emit_small moves the block to its place once the split event of the subtree's root is known.
+// (One THREAD per subtree, private bins in scratch memory, was the first version: 35 of the 72 ms of a 10 M-triangle
+// build; this one 16 of 54, and the larger the subtrees it takes the better up to 128 — 256 and 512 measured slower.)
+struct SmallShared {
+    Rec rec[kSmall];
+    Bins bins;
+    uint32_t ck[6];      // centre bounds of the node
+    uint32_t cbk[2][6];  // bounds of the two children
+    uint32_t zs[2][6];
+    uint32_t lpos[kSmall];
+    int stack_id[kSmall + 2];
+    uint32_t stack_depth[kSmall + 2], stack_rel[kSmall + 2], stack_count[kSmall + 2];
+    float stack_box[kSmall + 2][6];
+};
+
+__global__ __launch_bounds__(64) void k_small_wave(const uint32_t* __restrict__ small_list, const uint32_t* __restrict__ small_level, uint32_t n_small,
+                                                   const BNode* __restrict__ nodes, const Rec* __restrict__ small_rec, pt_bvh_node* small_nodes,
+                                                   uint32_t* small_splits, uint32_t* final_idx, uint32_t* counters) {
+    __shared__ SmallShared sh;
+    const uint32_t t = blockIdx.x;  // one subtree per block of one wave, so the barriers below are uniform
+    const uint32_t lane = threadIdx.x;
     const uint32_t v = small_list[t];
     const BNode root = nodes[v];
     pt_bvh_node* out = small_nodes + 2 * (size_t)root.first;
-    int stack_id[kSmall + 2];
-    uint32_t stack_depth[kSmall + 2];
-    int sp = 0;
-    stack_id[sp] = -1;
-    stack_depth[sp++] = 1;
+    for (uint32_t i = lane; i < root.count; i += 64) sh.rec[i] = small_rec[root.first + i];
+    if (lane == 0) {
+        sh.stack_id[0] = -1;
+        sh.stack_depth[0] = 1;
+        sh.stack_rel[0] = 0;
+        sh.stack_count[0] = root.count;
+        for (int a = 0; a < 3; ++a) { sh.stack_box[0][a] = key2f(root.bmin[a]); sh.stack_box[0][3 + a] = key2f(root.bmax[a]); }
+    }
+    int sp = 1;
     uint32_t nsplit = 0, maxd = 1;
     bool hazard = false;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    __syncthreads();
     while (sp > 0) {
-        const int id = stack_id[--sp];
-        const uint32_t d = stack_depth[sp];
-        uint32_t first, count;
+        --sp;
+        const int id = sh.stack_id[sp];
+        const uint32_t d = sh.stack_depth[sp], rel = sh.stack_rel[sp], count = sh.stack_count[sp];
         DBox nb, cb;
-        if (id < 0) {
-            first = root.first;
-            count = root.count;
-            for (int a = 0; a < 3; ++a) {
-                nb.lo[a] = key2f(root.bmin[a]); nb.hi[a] = key2f(root.bmax[a]);
-                cb.lo[a] = key2f(root.cmin[a]); cb.hi[a] = key2f(root.cmax[a]);
-            }
-        } else {
-            const pt_bvh_node nd = out[id];
-            first = nd.left_first;
-            count = nd.count;
-            if (count <= 2) continue;
-            for (int a = 0; a < 3; ++a) { nb.lo[a] = nd.min[a]; nb.hi[a] = nd.max[a]; }
-            cb.clear();
-            for (uint32_t i = first; i < first + count; ++i) cb.grow(small_rec[i].c, small_rec[i].c);
-        }
+        for (int a = 0; a < 3; ++a) { nb.lo[a] = sh.stack_box[sp][a]; nb.hi[a] = sh.stack_box[sp][3 + a]; }
         if (count <= 2) continue;
+        if (id < 0) {
+            for (int a = 0; a < 3; ++a) { cb.lo[a] = key2f(root.cmin[a]); cb.hi[a] = key2f(root.cmax[a]); }
+        } else {
+            __syncthreads();
+            if (lane < 6) sh.ck[lane] = lane < 3 ? kKeyPosInf : kKeyNegInf;
+            __syncthreads();
+            for (uint32_t i = lane; i < count; i += 64)
+                for (int a = 0; a < 3; ++a) {
+                    const float c = sh.rec[rel + i].c[a];
+                    key_min(&sh.ck[a], c);
+                    key_max(&sh.ck[3 + a], c);
+                }
+            __syncthreads();
+            for (int a = 0; a < 3; ++a) { cb.lo[a] = key2f(sh.ck[a]); cb.hi[a] = key2f(sh.ck[3 + a]); }
+        }
         // choose_split, bvh.rs:104-169
-        const float parent_cost = nb.area() * (float)count;
+        for (uint32_t w = lane; w < (uint32_t)kBinWords; w += 64) ((uint32_t*)&sh.bins)[w] = bin_identity((int)w);
+        __syncthreads();
         float delta[3];
         for (int a = 0; a < 3; ++a) delta[a] = (cb.hi[a] - cb.lo[a]) / 8.0f;
-        int best_axis = -1, best_bin = -1;
+        for (uint32_t i = lane; i < count; i += 64) {
+            const Rec r = sh.rec[rel + i];
+            for (int a = 0; a < 3; ++a) {
+                const float q = (r.c[a] - cb.lo[a]) / delta[a];
+                const int b = a * 8 + (int)fminf(fmaxf(q, 0.0f), 7.0f);
+                for (int k = 0; k < 3; ++k) {
+                    key_min(&sh.bins.mn[b][k], r.mn[k]);
+                    key_max(&sh.bins.mx[b][k], r.mx[k]);
+                }
+                atomicAdd(&sh.bins.n[b], 1u);
+            }
+        }
+        __syncthreads();
+        const float parent_cost = nb.area() * (float)count;
         float best = parent_cost;
-        for (int a = 0; a < 3; ++a) {
+        int best_axis = -1, best_bin = -1;
+        if (lane < 3) {
             DBox bb[8];
             uint32_t bn[8];
-            for (int k = 0; k < 8; ++k) { bb[k].clear(); bn[k] = 0; }
-            for (uint32_t i = first; i < first + count; ++i) {
-                const Rec& r = small_rec[i];
-                const float q = (r.c[a] - cb.lo[a]) / delta[a];
-                const int b = (int)fminf(fmaxf(q, 0.0f), 7.0f);
-                bb[b].grow(r.mn, r.mx);
-                bn[b] += 1;
+            for (int k = 0; k < 8; ++k) {
+                for (int c = 0; c < 3; ++c) { bb[k].lo[c] = key2f(sh.bins.mn[lane * 8 + k][c]); bb[k].hi[c] = key2f(sh.bins.mx[lane * 8 + k][c]); }
+                bn[k] = sh.bins.n[lane * 8 + k];
             }
-            sah_axis(bb, bn, a, best, best_axis, best_bin);
+            sah_axis(bb, bn, (int)lane, best, best_axis, best_bin);
         }
-        if (best_axis < 0) continue;
-        const float pivot = cb.lo[best_axis] + (float)(1 + best_bin) * delta[best_axis];
+        int axis = -1, bin = -1;
+        float run = parent_cost;
+        for (int a = 0; a < 3; ++a) {  // the sweep goes on with the best cost so far, axis after axis
+            const float c = __shfl(best, a, 64);
+            const int found = __shfl(best_axis, a, 64), b = __shfl(best_bin, a, 64);
+            if (found >= 0 && c < run) { run = c; axis = a; bin = b; }
+        }
+        if (axis < 0) continue;
+        const float pivot = (axis == 0 ? cb.lo[0] : axis == 1 ? cb.lo[1] : cb.lo[2]) + (float)(1 + bin) * (axis == 0 ? delta[0] : axis == 1 ? delta[1] : delta[2]);
         // partition, bvh.rs:63-103
-        DBox lb, rb;
-        lb.clear();
-        rb.clear();
-        uint32_t split = first;
-        for (uint32_t i = first; i < first + count; ++i) {
-            const Rec r = small_rec[i];
-            if (r.c[best_axis] <= pivot) {
-                lb.grow(r.mn, r.mx);
-                small_rec[i] = small_rec[split];
-                small_rec[split] = r;
-                split += 1;
+        Rec r[kSmallPerLane];
+        bool val[kSmallPerLane], fl[kSmallPerLane];
+        uint32_t rank[kSmallPerLane], nl = 0;
+#pragma unroll
+        for (int h = 0; h < kSmallPerLane; ++h) {
+            val[h] = lane + 64u * h < count;
+            r[h] = sh.rec[rel + (val[h] ? lane + 64u * h : 0u)];
+            const float c = axis == 0 ? r[h].c[0] : axis == 1 ? r[h].c[1] : r[h].c[2];
+            fl[h] = val[h] && c <= pivot;
+            const unsigned long long m = __ballot(fl[h]);
+            rank[h] = nl + (uint32_t)__popcll(m & lt);
+            nl += (uint32_t)__popcll(m);
+            if (fl[h]) sh.lpos[rank[h]] = lane + 64u * h;
+        }
+        if (lane < 12) {
+            (&sh.cbk[0][0])[lane] = (lane % 6) < 3 ? kKeyPosInf : kKeyNegInf;
+            (&sh.zs[0][0])[lane] = kNone;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < kSmallPerLane; ++h) {
+            if (!val[h]) continue;
+            const uint32_t p = lane + 64u * h;
+            uint32_t q;
+            if (fl[h]) {
+                q = rank[h];
             } else {
-                rb.grow(r.mn, r.mx);
+                q = p;
+                while (q < nl) q = sh.lpos[q];
+            }
+            sh.rec[rel + q] = r[h];
+            const uint32_t right = q >= nl ? 1u : 0u;
+            for (int a = 0; a < 3; ++a) {
+                key_min(&sh.cbk[right][a], r[h].mn[a]);
+                key_max(&sh.cbk[right][3 + a], r[h].mx[a]);
+                zero_vote(&sh.zs[right][a], r[h].mn[a], p);
+                zero_vote(&sh.zs[right][3 + a], r[h].mx[a], p);
             }
         }
-        const uint32_t nl = split - first;
+        __syncthreads();
         hazard = hazard || nl == 0 || nl == count;
         const uint32_t L = 2 * nsplit;
-        pt_bvh_node c;
-        for (int a = 0; a < 3; ++a) { c.min[a] = lb.lo[a]; c.max[a] = lb.hi[a]; }
-        c.left_first = first;
-        c.count = nl;
-        out[L] = c;
-        for (int a = 0; a < 3; ++a) { c.min[a] = rb.lo[a]; c.max[a] = rb.hi[a]; }
-        c.left_first = first + nl;
-        c.count = count - nl;
-        out[L + 1] = c;
-        if (id >= 0) {  // the node becomes internal: link to its children's block places
-            out[id].left_first = L;
-            out[id].count = 0;
+        float box[2][6];
+        for (int ch = 0; ch < 2; ++ch)
+            for (int a = 0; a < 6; ++a) {
+                float f = key2f(sh.cbk[ch][a]);
+                if (f == 0.0f && sh.zs[ch][a] != kNone && (sh.zs[ch][a] & 1u)) f = -0.0f;
+                box[ch][a] = f;
+            }
+        if (lane == 0) {
+            pt_bvh_node c;
+            for (int a = 0; a < 3; ++a) { c.min[a] = box[0][a]; c.max[a] = box[0][3 + a]; }
+            c.left_first = root.first + rel;
+            c.count = nl;
+            out[L] = c;
+            for (int a = 0; a < 3; ++a) { c.min[a] = box[1][a]; c.max[a] = box[1][3 + a]; }
+            c.left_first = root.first + rel + nl;
+            c.count = count - nl;
+            out[L + 1] = c;
+            if (id >= 0) {  // the node becomes internal: link to its children's block places
+                out[id].left_first = L;
+                out[id].count = 0;
+            }
         }
         nsplit += 1;
         maxd = max(maxd, d + 1);
         if (nsplit >= kSmall) break;  // cannot happen without the empty-child hazard (at most count - 1 splits)
-        stack_id[sp] = (int)L + 1;
-        stack_depth[sp++] = d + 1;
-        stack_id[sp] = (int)L;
-        stack_depth[sp++] = d + 1;
+        if (lane == 0) {
+            for (int ch = 1; ch >= 0; --ch) {  // the left child is split first: pushed last
+                const int e = sp + (1 - ch);
+                sh.stack_id[e] = (int)L + ch;
+                sh.stack_depth[e] = d + 1;
+                sh.stack_rel[e] = ch ? rel + nl : rel;
+                sh.stack_count[e] = ch ? count - nl : nl;
+                for (int a = 0; a < 6; ++a) sh.stack_box[e][a] = box[ch][a];
+            }
+        }
+        sp += 2;
+        __syncthreads();
     }
-    small_splits[v] = nsplit;
-    for (uint32_t i = root.first; i < root.first + root.count; ++i) final_idx[i] = small_rec[i].idx;
-    atomicMax(&counters[5], small_level[t] + maxd - 1);
-    if (hazard) atomicOr(&counters[2], 1u);
+    __syncthreads();
+    for (uint32_t i = lane; i < root.count; i += 64) final_idx[root.first + i] = sh.rec[i].idx;
+    if (lane == 0) {
+        small_splits[v] = nsplit;
+        atomicMax(&counters[5], small_level[t] + maxd - 1);
+        if (hazard) atomicOr(&counters[2], 1u);
+    }
 }
 
 __global__ void k_emit_small(const uint32_t* __restrict__ small_list, uint32_t n_small, const BNode* __restrict__ nodes, const pt_bvh_node* __restrict__ small_nodes,
@@ -498,7 +590,7 @@ __global__ void k_scan_apply(const uint32_t* __restrict__ flags, uint32_t n, con
 __device__ __forceinline__ uint32_t child_slot(uint32_t count, uint32_t id, uint32_t level, uint32_t* counters, uint32_t* next_active, uint32_t* small_list,
                                                uint32_t* small_level, uint32_t small_limit) {
     if (count <= 2) return kNone;  // never split
-    if (count <= small_limit) {    // one thread finishes it (k_small)
+    if (count <= small_limit) {    // one wave finishes it (k_small_wave)
         const uint32_t k = atomicAdd(&counters[4], 1u);
         small_list[k] = id;
         small_level[k] = level;
@@ -663,7 +755,7 @@ __global__ void k_emit(const BNode* __restrict__ nodes, uint32_t n_nodes, const 
         if (o.min[a] == 0.0f && nd.zs[a] != kNone && (nd.zs[a] & 1u)) o.min[a] = -0.0f;
         if (o.max[a] == 0.0f && nd.zs[3 + a] != kNone && (nd.zs[3 + a] & 1u)) o.max[a] = -0.0f;
     }
-    const bool small_split = !nd.left && small_splits[v] != 0;  // split by k_small: its children head its block
+    const bool small_split = !nd.left && small_splits[v] != 0;  // split by k_small_wave: its children head its block
     o.left_first = nd.left ? newid[nd.left] : (small_split ? 1 + 2 * event[v] : nd.first);
     o.count = (nd.left || small_split) ? 0u : nd.count;
     out[newid[v]] = o;
@@ -840,13 +932,12 @@ int build_bvh_device(int prim_kind, const float* d_geom, uint32_t n, DeviceTree&
     BUILD_HIP(hipGetLastError());
     tick("alloc, records, root");
     std::vector<uint32_t> level_start{0, 1};  // node ids of level L are [level_start[L], level_start[L + 1])
-    // Subtrees of at most small_limit primitives are finished by one thread each.  Larger is cheaper per primitive (fewer
-    // levels of atomics) as long as there are enough such threads to fill the GPU: 10 M triangles 72 ms at 128 (90 at 32,
-    // 86 at 256), 871 k triangles 13 ms at 32 (24 at 128).
-    const uint32_t small_limit = std::min<uint32_t>(kSmall, std::max<uint32_t>(16, n >> 16));
+    // Subtrees of at most kSmall primitives are finished by one wave each (k_small_wave).  Measured with limits of 16 / 32 /
+    // 64 / 128 / 256 / 512: 10 M triangles 85 / 74 / 62 / 54 / 60 / 100 ms, 871 k triangles 12.8 / 11.9 / 10.7 / 9.8 / 11.0 / 15.3 ms.
+    const uint32_t small_limit = kSmall;
     uint32_t n_active = n > small_limit ? 1 : 0;
     Buf *rc = &rec_a, *rn = &rec_b, *sc = &seg_a, *sn = &seg_b, *ac = &act_a, *an = &act_b;
-    if (n > 2 && n <= small_limit) {  // the root itself is a small subtree: one thread builds all of it
+    if (n > 2 && n <= small_limit) {  // the root itself is a small subtree: one wave builds all of it
         const uint32_t one[2] = {0u, 1u};
         BUILD_HIP(hipMemcpyAsync(small_list.p, &one[0], 4, hipMemcpyHostToDevice, st));
         BUILD_HIP(hipMemcpyAsync(small_level.p, &one[1], 4, hipMemcpyHostToDevice, st));
@@ -892,7 +983,7 @@ int build_bvh_device(int prim_kind, const float* d_geom, uint32_t n, DeviceTree&
     BUILD_HIP(hipStreamSynchronize(st));
     const uint32_t n_small = h_cnt[4];
     if (n_small)
-        hipLaunchKernelGGL(k_small, dim3(blocks(n_small)), dim3(kBlock), 0, st, small_list.as<uint32_t>(), small_level.as<uint32_t>(), n_small, nodes.as<BNode>(),
+        hipLaunchKernelGGL(k_small_wave, dim3(n_small), dim3(64), 0, st, small_list.as<uint32_t>(), small_level.as<uint32_t>(), n_small, nodes.as<BNode>(),
                            small_rec.as<Rec>(), small_nodes.as<pt_bvh_node>(), small_splits.as<uint32_t>(), final_idx.as<uint32_t>(), counters.as<uint32_t>());
 
     BUILD_HIP(splits.alloc((size_t)n_level_nodes * 4));
