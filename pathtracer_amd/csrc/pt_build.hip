@@ -187,9 +187,10 @@ __global__ void k_init_bins(Bins* bins, uint32_t n_active) {
     ((uint32_t*)bins)[i] = w < 72 ? kKeyPosInf : (w < 144 ? kKeyNegInf : 0u);
 }
 
-// ---- binning.  Positions of one node are contiguous, so a whole workgroup or at least a whole wave usually lies inside
-// one node: such a wave reduces into its own LDS bins, which are flushed with one global atomic per touched word (per
-// workgroup when all of it is one node).  Only waves that straddle nodes update the global bins per primitive.
+// ---- binning.  Positions of one node are contiguous, so a whole workgroup usually lies inside one node and a wave in at
+// most two: a wave reduces into its own LDS bins (one set per node), which are flushed with one global atomic per touched
+// word (per workgroup when all of it is one node).  Only a wave with three or more nodes (nodes shorter than a wave: not
+// with the small subtrees handed off at 128) updates the global bins per primitive.
 constexpr int kWaves = kBlock / 64;
 
 __device__ __forceinline__ uint32_t bin_identity(int w) { return w < 72 ? kKeyPosInf : (w < 144 ? kKeyNegInf : 0u); }
@@ -199,23 +200,41 @@ __device__ __forceinline__ void bin_flush(uint32_t* g, int w, uint32_t v) {
     else if (v) atomicAdd(g + w, v);
 }
 
+// The active lanes of a wave (positions of unfinished nodes) belong to at most two nodes whenever nodes are longer than a
+// wave — finished positions may lie in between: such a wave keeps one set of LDS accumulators per node.
+struct WaveSegs {
+    uint32_t a, b;  // slot of the first / last active lane's node (kNone: no active lane)
+    bool two;       // every active lane is in a or b
+};
+__device__ __forceinline__ WaveSegs wave_segs(uint32_t s) {
+    WaveSegs w;
+    const unsigned long long am = __ballot(s != kNone);
+    w.a = w.b = kNone;
+    if (am) {
+        w.a = __shfl(s, __ffsll((long long)am) - 1, 64);
+        w.b = __shfl(s, 63 - __clzll((long long)am), 64);
+    }
+    w.two = __all((s == kNone || s == w.a || s == w.b) ? 1 : 0) != 0;
+    return w;
+}
+
 __global__ void k_bin(const Rec* __restrict__ rec, const uint32_t* __restrict__ seg, uint32_t n, const BNode* __restrict__ nodes,
                       const uint32_t* __restrict__ active, Bins* bins) {
-    __shared__ uint32_t lb[kWaves][kBinWords];
+    __shared__ uint32_t lb[kWaves][2][kBinWords];
     __shared__ uint32_t s0;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t s = i < n ? seg[i] : kNone;
     if (threadIdx.x == 0) s0 = s;
-    for (int w = threadIdx.x; w < kWaves * kBinWords; w += blockDim.x) (&lb[0][0])[w] = bin_identity(w % kBinWords);
+    for (int w = threadIdx.x; w < kWaves * 2 * kBinWords; w += blockDim.x) (&lb[0][0][0])[w] = bin_identity(w % kBinWords);
     __syncthreads();
-    const uint32_t block_s = s0, wave_s = __shfl(s, 0, 64);
+    const WaveSegs ws = wave_segs(s);
+    const uint32_t block_s = s0;
     const bool block_uniform = __syncthreads_and((i >= n || s == block_s) ? 1 : 0) != 0 && block_s != kNone;
-    const bool wave_uniform = __all((i >= n || s == wave_s) ? 1 : 0) != 0 && wave_s != kNone;
     if (s != kNone) {
         const BNode& nd = nodes[active[s]];
         const Rec r = rec[i];
-        Bins* B = wave_uniform ? (Bins*)lb[wave] : bins + s;
+        Bins* B = ws.two ? (Bins*)lb[wave][s == ws.a ? 0 : 1] : bins + s;
         for (int a = 0; a < 3; ++a) {
             const float lo = key2f(nd.cmin[a]), hi = key2f(nd.cmax[a]);
             const float delta = (hi - lo) / 8.0f;                 // bvh.rs:121-123
@@ -232,13 +251,15 @@ __global__ void k_bin(const Rec* __restrict__ rec, const uint32_t* __restrict__ 
     if (block_uniform) {  // every wave is inside the one node (or past the end): combine the slices, one flush
         uint32_t* g = (uint32_t*)(bins + block_s);
         for (int w = threadIdx.x; w < kBinWords; w += blockDim.x) {
-            uint32_t v = lb[0][w];
-            for (int k = 1; k < kWaves; ++k) v = w < 72 ? min(v, lb[k][w]) : (w < 144 ? max(v, lb[k][w]) : v + lb[k][w]);
+            uint32_t v = lb[0][0][w];
+            for (int k = 1; k < kWaves; ++k) v = w < 72 ? min(v, lb[k][0][w]) : (w < 144 ? max(v, lb[k][0][w]) : v + lb[k][0][w]);
             bin_flush(g, w, v);
         }
-    } else if (wave_uniform) {
-        uint32_t* g = (uint32_t*)(bins + wave_s);
-        for (int w = lane; w < kBinWords; w += 64) bin_flush(g, w, lb[wave][w]);
+    } else if (ws.two) {
+        if (ws.a != kNone)
+            for (int w = lane; w < kBinWords; w += 64) bin_flush((uint32_t*)(bins + ws.a), w, lb[wave][0][w]);
+        if (ws.b != ws.a)
+            for (int w = lane; w < kBinWords; w += 64) bin_flush((uint32_t*)(bins + ws.b), w, lb[wave][1][w]);
     }
 }
 
@@ -650,17 +671,17 @@ __global__ void k_lpos(const uint32_t* __restrict__ seg, uint32_t n, const uint3
 __global__ void k_scatter(const Rec* __restrict__ rec, const uint32_t* __restrict__ seg, uint32_t n, const uint32_t* __restrict__ flags,
                           const uint32_t* __restrict__ P, const uint32_t* __restrict__ lpos, const uint32_t* __restrict__ active, BNode* nodes,
                           const Split* __restrict__ split, Rec* rec_next, uint32_t* seg_next, uint32_t* final_idx, Rec* small_rec) {
-    __shared__ uint32_t acc[kWaves][24];  // [child][bmin3 bmax3 cmin3 cmax3]
+    __shared__ uint32_t acc[kWaves][2][24];  // per wave and node of the wave: [child][bmin3 bmax3 cmin3 cmax3]
     __shared__ uint32_t s0;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t s = i < n ? seg[i] : kNone;
     if (threadIdx.x == 0) s0 = s;
-    if (threadIdx.x < kWaves * 24) (&acc[0][0])[threadIdx.x] = (threadIdx.x % 6) < 3 ? kKeyPosInf : kKeyNegInf;
+    if (threadIdx.x < kWaves * 48) (&acc[0][0][0])[threadIdx.x] = (threadIdx.x % 6) < 3 ? kKeyPosInf : kKeyNegInf;
     __syncthreads();
-    const uint32_t block_s = s0, wave_s = __shfl(s, 0, 64);
+    const WaveSegs ws = wave_segs(s);
+    const uint32_t block_s = s0;
     const bool block_uniform = __syncthreads_and((i >= n || s == block_s) ? 1 : 0) != 0 && block_s != kNone;
-    const bool wave_uniform = __all((i >= n || s == wave_s) ? 1 : 0) != 0 && wave_s != kNone;
     if (i < n) {
         if (s == kNone) {
             seg_next[i] = kNone;
@@ -686,7 +707,7 @@ __global__ void k_scatter(const Rec* __restrict__ rec, const uint32_t* __restric
                 else if (cs == kSmallSlot) small_rec[dest] = r;
                 else rec_next[dest] = r;
                 seg_next[dest] = cs == kSmallSlot ? kNone : cs;
-                uint32_t* b = wave_uniform ? acc[wave] + 12 * right : nodes[sp.pair + right].bmin;  // bmin, bmax, cmin, cmax are consecutive
+                uint32_t* b = ws.two ? acc[wave][s == ws.a ? 0 : 1] + 12 * right : nodes[sp.pair + right].bmin;  // bmin, bmax, cmin, cmax are consecutive
                 uint32_t* zs = nodes[sp.pair + right].zs;
                 for (int a = 0; a < 3; ++a) {
                     key_min(b + a, r.mn[a]);
@@ -704,19 +725,21 @@ __global__ void k_scatter(const Rec* __restrict__ rec, const uint32_t* __restric
     if (block_uniform) {
         if (threadIdx.x < 24) {
             const bool is_min = (threadIdx.x % 6) < 3;
-            uint32_t v = acc[0][threadIdx.x];
-            for (int k = 1; k < kWaves; ++k) v = is_min ? min(v, acc[k][threadIdx.x]) : max(v, acc[k][threadIdx.x]);
+            uint32_t v = acc[0][0][threadIdx.x];
+            for (int k = 1; k < kWaves; ++k) v = is_min ? min(v, acc[k][0][threadIdx.x]) : max(v, acc[k][0][threadIdx.x]);
             if (v != (is_min ? kKeyPosInf : kKeyNegInf)) {
                 uint32_t* dst = nodes[split[block_s].pair + threadIdx.x / 12].bmin + threadIdx.x % 12;
                 if (is_min) atomicMin(dst, v);
                 else atomicMax(dst, v);
             }
         }
-    } else if (wave_uniform && lane < 24) {
-        const bool is_min = (lane % 6) < 3;
-        const uint32_t v = acc[wave][lane];
-        if (v != (is_min ? kKeyPosInf : kKeyNegInf)) {
-            uint32_t* dst = nodes[split[wave_s].pair + lane / 12].bmin + lane % 12;
+    } else if (ws.two && lane < 48) {
+        const int which = lane / 24, w = lane % 24;
+        const uint32_t node_s = which ? ws.b : ws.a;
+        const bool is_min = (w % 6) < 3;
+        const uint32_t v = acc[wave][which][w];
+        if (node_s != kNone && !(which && ws.b == ws.a) && v != (is_min ? kKeyPosInf : kKeyNegInf)) {
+            uint32_t* dst = nodes[split[node_s].pair + w / 12].bmin + w % 12;
             if (is_min) atomicMin(dst, v);
             else atomicMax(dst, v);
         }
