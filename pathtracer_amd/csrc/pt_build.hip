@@ -320,25 +320,27 @@ __global__ void k_sah(const uint32_t* __restrict__ active, uint32_t n_active, co
 }
 
 // ---- one WAVE finishes the subtree of a node of at most kSmall primitives, depth first as the reference does
-// (bvh.rs:52-103 with its explicit stack).  The subtree's records live in LDS; every phase of a node (centre bounds,
-// bins, flags, places, child bounds) runs over its primitives two per lane, the sweep on three lanes (one per axis,
-// combined in axis order with the sweep's own strict <), and the order inside the two halves comes from the flags by
-// the rule of k_lpos / k_scatter.  Bounds are reduced as keys with zero votes (position in the node = the order in
-// which the reference's walk meets the objects), exactly as for the large nodes.  The subtree's nodes go to a private
-// block — the children of its k-th split at block places 2k and 2k + 1, which is the reference's numbering relative
-// to the block — and k_emit_small moves the block to its place once the split event of the subtree's root is known.
+// (bvh.rs:52-103 with its explicit stack).  The subtree's records live in LDS; every phase of a node (bins, flags,
+// places, the children's bounds and centre bounds) runs over its primitives two per lane, the sweep one candidate
+// (axis, bin) per lane, and the order inside the two halves comes from the flags by the rule of k_lpos / k_scatter.
+// Bounds are reduced as keys with zero votes (position in the node = the order in which the reference's walk meets the
+// objects), exactly as for the large nodes.  The subtree's nodes go to a private block — the children of its k-th
+// split at block places 2k and 2k + 1, which is the reference's numbering relative to the block — and k_emit_small
+// moves the block to its place once the split event of the subtree's root is known.
 // (One THREAD per subtree, private bins in scratch memory, was the first version: 35 of the 72 ms of a 10 M-triangle
-// build; this one 16 of 54, and the larger the subtrees it takes the better up to 128 — 256 and 512 measured slower.)
+// build; one wave with the sweep on three lanes and a pass of its own for the centre bounds 16 of 54; this one 11 of
+// 41.  The larger the subtrees it takes the better up to 128 — 256 and 512 measured slower, before and after.)
+constexpr int kSmallStack = kSmall / 3 + 3;  // pending nodes are disjoint and hold at least three primitives each
 struct SmallShared {
     Rec rec[kSmall];
     Bins bins;
-    uint32_t ck[6];      // centre bounds of the node
     uint32_t cbk[2][6];  // bounds of the two children
+    uint32_t cck[2][6];  // bounds of their centres
     uint32_t zs[2][6];
     uint32_t lpos[kSmall];
-    int stack_id[kSmall + 2];
-    uint32_t stack_depth[kSmall + 2], stack_rel[kSmall + 2], stack_count[kSmall + 2];
-    float stack_box[kSmall + 2][6];
+    int stack_id[kSmallStack];
+    uint32_t stack_depth[kSmallStack], stack_rel[kSmallStack], stack_count[kSmallStack];
+    float stack_box[kSmallStack][12];  // node bounds (min, max), centre bounds (min, max)
 };
 
 __global__ __launch_bounds__(64) void k_small_wave(const uint32_t* __restrict__ small_list, const uint32_t* __restrict__ small_level, uint32_t n_small,
@@ -356,34 +358,24 @@ __global__ __launch_bounds__(64) void k_small_wave(const uint32_t* __restrict__ 
         sh.stack_depth[0] = 1;
         sh.stack_rel[0] = 0;
         sh.stack_count[0] = root.count;
-        for (int a = 0; a < 3; ++a) { sh.stack_box[0][a] = key2f(root.bmin[a]); sh.stack_box[0][3 + a] = key2f(root.bmax[a]); }
+        for (int a = 0; a < 3; ++a) {
+            sh.stack_box[0][a] = key2f(root.bmin[a]); sh.stack_box[0][3 + a] = key2f(root.bmax[a]);
+            sh.stack_box[0][6 + a] = key2f(root.cmin[a]); sh.stack_box[0][9 + a] = key2f(root.cmax[a]);
+        }
     }
     int sp = 1;
     uint32_t nsplit = 0, maxd = 1;
     bool hazard = false;
     const unsigned long long lt = (1ull << lane) - 1ull;
     __syncthreads();
-    while (sp > 0) {
+    while (sp > 0) {  // (only nodes of three or more primitives are ever pushed: the others are never split, bvh.rs:56)
         --sp;
         const int id = sh.stack_id[sp];
         const uint32_t d = sh.stack_depth[sp], rel = sh.stack_rel[sp], count = sh.stack_count[sp];
         DBox nb, cb;
-        for (int a = 0; a < 3; ++a) { nb.lo[a] = sh.stack_box[sp][a]; nb.hi[a] = sh.stack_box[sp][3 + a]; }
-        if (count <= 2) continue;
-        if (id < 0) {
-            for (int a = 0; a < 3; ++a) { cb.lo[a] = key2f(root.cmin[a]); cb.hi[a] = key2f(root.cmax[a]); }
-        } else {
-            __syncthreads();
-            if (lane < 6) sh.ck[lane] = lane < 3 ? kKeyPosInf : kKeyNegInf;
-            __syncthreads();
-            for (uint32_t i = lane; i < count; i += 64)
-                for (int a = 0; a < 3; ++a) {
-                    const float c = sh.rec[rel + i].c[a];
-                    key_min(&sh.ck[a], c);
-                    key_max(&sh.ck[3 + a], c);
-                }
-            __syncthreads();
-            for (int a = 0; a < 3; ++a) { cb.lo[a] = key2f(sh.ck[a]); cb.hi[a] = key2f(sh.ck[3 + a]); }
+        for (int a = 0; a < 3; ++a) {
+            nb.lo[a] = sh.stack_box[sp][a]; nb.hi[a] = sh.stack_box[sp][3 + a];
+            cb.lo[a] = sh.stack_box[sp][6 + a]; cb.hi[a] = sh.stack_box[sp][9 + a];
         }
         // choose_split, bvh.rs:104-169
         for (uint32_t w = lane; w < (uint32_t)kBinWords; w += 64) ((uint32_t*)&sh.bins)[w] = bin_identity((int)w);
@@ -403,26 +395,42 @@ __global__ __launch_bounds__(64) void k_small_wave(const uint32_t* __restrict__ 
             }
         }
         __syncthreads();
+        // the sweep of bvh.rs:135-168, one candidate (axis, bin) per lane: the reference takes a candidate when its cost is
+        // below the best so far, axis after axis and bin after bin, i.e. the FIRST candidate with the smallest cost, if
+        // that is below the parent's; a NaN cost is never taken
         const float parent_cost = nb.area() * (float)count;
-        float best = parent_cost;
-        int best_axis = -1, best_bin = -1;
-        if (lane < 3) {
-            DBox bb[8];
-            uint32_t bn[8];
-            for (int k = 0; k < 8; ++k) {
-                for (int c = 0; c < 3; ++c) { bb[k].lo[c] = key2f(sh.bins.mn[lane * 8 + k][c]); bb[k].hi[c] = key2f(sh.bins.mx[lane * 8 + k][c]); }
-                bn[k] = sh.bins.n[lane * 8 + k];
+        float cost = 0.0f;
+        bool cand = false;
+        if (lane < 24) {
+            const uint32_t a8 = lane & ~7u, k = lane & 7u;
+            DBox left, right;
+            left.clear();
+            right.clear();
+            uint32_t nleft = 0, nright = 0;
+            for (uint32_t j = 0; j < 8; ++j) {
+                DBox bj;
+                for (int c = 0; c < 3; ++c) { bj.lo[c] = key2f(sh.bins.mn[a8 + j][c]); bj.hi[c] = key2f(sh.bins.mx[a8 + j][c]); }
+                const uint32_t nj = sh.bins.n[a8 + j];
+                if (j <= k) { left.grow(bj); nleft += nj; }
+                if (j >= k) { right.grow(bj); nright += nj; }  // right side includes bin k, bvh.rs:155
             }
-            sah_axis(bb, bn, (int)lane, best, best_axis, best_bin);
+            cost = (float)nleft * left.area() + (float)nright * right.area();
+            cand = cost < parent_cost;
         }
-        int axis = -1, bin = -1;
-        float run = parent_cost;
-        for (int a = 0; a < 3; ++a) {  // the sweep goes on with the best cost so far, axis after axis
-            const float c = __shfl(best, a, 64);
-            const int found = __shfl(best_axis, a, 64), b = __shfl(best_bin, a, 64);
-            if (found >= 0 && c < run) { run = c; axis = a; bin = b; }
+        uint32_t who = lane;
+        if (!cand) cost = __builtin_inff();
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) {  // lanes 0 .. 31: smallest cost, the lower lane on a tie
+            const float oc = __shfl_xor(cost, off, 64);
+            const uint32_t ow = __shfl_xor(who, off, 64);
+            const bool ocand = __shfl_xor((int)cand, off, 64) != 0;
+            const bool take = ocand && (!cand || oc < cost || (oc == cost && ow < who));
+            if (take) { cost = oc; who = ow; cand = true; }
         }
-        if (axis < 0) continue;
+        const bool any = __shfl((int)cand, 0, 64) != 0;
+        if (!any) continue;
+        const uint32_t win = (uint32_t)__shfl((int)who, 0, 64);
+        const int axis = (int)(win >> 3), bin = (int)(win & 7u);
         const float pivot = (axis == 0 ? cb.lo[0] : axis == 1 ? cb.lo[1] : cb.lo[2]) + (float)(1 + bin) * (axis == 0 ? delta[0] : axis == 1 ? delta[1] : delta[2]);
         // partition, bvh.rs:63-103
         Rec r[kSmallPerLane];
@@ -441,6 +449,7 @@ __global__ __launch_bounds__(64) void k_small_wave(const uint32_t* __restrict__ 
         }
         if (lane < 12) {
             (&sh.cbk[0][0])[lane] = (lane % 6) < 3 ? kKeyPosInf : kKeyNegInf;
+            (&sh.cck[0][0])[lane] = (lane % 6) < 3 ? kKeyPosInf : kKeyNegInf;
             (&sh.zs[0][0])[lane] = kNone;
         }
         __syncthreads();
@@ -460,6 +469,8 @@ __global__ __launch_bounds__(64) void k_small_wave(const uint32_t* __restrict__ 
             for (int a = 0; a < 3; ++a) {
                 key_min(&sh.cbk[right][a], r[h].mn[a]);
                 key_max(&sh.cbk[right][3 + a], r[h].mx[a]);
+                key_min(&sh.cck[right][a], r[h].c[a]);
+                key_max(&sh.cck[right][3 + a], r[h].c[a]);
                 zero_vote(&sh.zs[right][a], r[h].mn[a], p);
                 zero_vote(&sh.zs[right][3 + a], r[h].mx[a], p);
             }
@@ -492,17 +503,23 @@ __global__ __launch_bounds__(64) void k_small_wave(const uint32_t* __restrict__ 
         nsplit += 1;
         maxd = max(maxd, d + 1);
         if (nsplit >= kSmall) break;  // cannot happen without the empty-child hazard (at most count - 1 splits)
+        const uint32_t cnt[2] = {nl, count - nl};
         if (lane == 0) {
+            int e = sp;
             for (int ch = 1; ch >= 0; --ch) {  // the left child is split first: pushed last
-                const int e = sp + (1 - ch);
+                if (cnt[ch] <= 2) continue;   // never split
                 sh.stack_id[e] = (int)L + ch;
                 sh.stack_depth[e] = d + 1;
                 sh.stack_rel[e] = ch ? rel + nl : rel;
-                sh.stack_count[e] = ch ? count - nl : nl;
-                for (int a = 0; a < 6; ++a) sh.stack_box[e][a] = box[ch][a];
+                sh.stack_count[e] = cnt[ch];
+                for (int a = 0; a < 6; ++a) {
+                    sh.stack_box[e][a] = box[ch][a];
+                    sh.stack_box[e][6 + a] = key2f(sh.cck[ch][a]);
+                }
+                e += 1;
             }
         }
-        sp += 2;
+        sp += (cnt[0] > 2 ? 1 : 0) + (cnt[1] > 2 ? 1 : 0);
         __syncthreads();
     }
     __syncthreads();
@@ -862,10 +879,33 @@ __global__ void k_flatten(const pt_bvh_node* __restrict__ nodes, uint32_t n_node
 
 struct Buf {
     void* p = nullptr;
-    ~Buf() { if (p) (void)hipFree(p); }
+    bool owned = true;  // false: a piece of an Arena
+    ~Buf() { if (p && owned) (void)hipFree(p); }
     hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
     template <class T> T* as() const { return (T*)p; }
     void* take() { void* q = p; p = nullptr; return q; }
+};
+
+// The temporaries of one build come out of ONE device allocation (two dozen hipMalloc / hipFree pairs cost 3 ms, a
+// quarter of the time of a 1 M-triangle tree): 256-byte aligned pieces, freed together.
+struct Arena {
+    char* base = nullptr;
+    std::vector<std::pair<Buf*, size_t>> want;
+    ~Arena() { if (base) (void)hipFree(base); }
+    void add(Buf& b, size_t bytes) { want.push_back({&b, (std::max<size_t>(bytes, 16) + 255) & ~(size_t)255}); }
+    hipError_t commit() {
+        size_t total = 0;
+        for (const auto& w : want) total += w.second;
+        hipError_t e = hipMalloc((void**)&base, total);
+        if (e != hipSuccess) return e;
+        size_t at = 0;
+        for (const auto& w : want) {
+            w.first->p = base + at;
+            w.first->owned = false;
+            at += w.second;
+        }
+        return hipSuccess;
+    }
 };
 
 // exclusive prefix sum of n flags into P[0..n]
@@ -923,26 +963,31 @@ int build_bvh_device(int prim_kind, const float* d_geom, uint32_t n, DeviceTree&
     const uint32_t max_nodes = 2 * n + 1, max_active = n / 3 + 2, nb = (n + kScanTile - 1) / kScanTile;
     Buf rec_a, rec_b, seg_a, seg_b, flags, P, lpos, sums, nodes, act_a, act_b, bins, split, counters, final_idx, splits, event, newid, outn;
     Buf small_rec, small_nodes, small_list, small_level, small_splits;
-    BUILD_HIP(rec_a.alloc((size_t)n * sizeof(Rec)));
-    BUILD_HIP(rec_b.alloc((size_t)n * sizeof(Rec)));
-    BUILD_HIP(seg_a.alloc((size_t)n * 4));
-    BUILD_HIP(seg_b.alloc((size_t)n * 4));
-    BUILD_HIP(flags.alloc((size_t)n * 4));
-    BUILD_HIP(P.alloc(((size_t)n + 1) * 4));
-    BUILD_HIP(lpos.alloc((size_t)n * 4));
-    BUILD_HIP(sums.alloc((size_t)nb * 4));
-    BUILD_HIP(nodes.alloc((size_t)max_nodes * sizeof(BNode)));
-    BUILD_HIP(act_a.alloc((size_t)max_active * 4));
-    BUILD_HIP(act_b.alloc((size_t)max_active * 4));
-    BUILD_HIP(bins.alloc((size_t)max_active * sizeof(Bins)));
-    BUILD_HIP(split.alloc((size_t)max_active * sizeof(Split)));
-    BUILD_HIP(counters.alloc(32));
-    BUILD_HIP(final_idx.alloc((size_t)n * 4));
-    BUILD_HIP(small_rec.alloc((size_t)n * sizeof(Rec)));
-    BUILD_HIP(small_nodes.alloc((size_t)n * 2 * sizeof(pt_bvh_node)));
-    BUILD_HIP(small_list.alloc((size_t)max_active * 4));
-    BUILD_HIP(small_level.alloc((size_t)max_active * 4));
-    BUILD_HIP(small_splits.alloc((size_t)max_nodes * 4));
+    Arena arena;  // declared after the Bufs: released first, while they still only point into it
+    arena.add(rec_a, (size_t)n * sizeof(Rec));
+    arena.add(rec_b, (size_t)n * sizeof(Rec));
+    arena.add(seg_a, (size_t)n * 4);
+    arena.add(seg_b, (size_t)n * 4);
+    arena.add(flags, (size_t)n * 4);
+    arena.add(P, ((size_t)n + 1) * 4);
+    arena.add(lpos, (size_t)n * 4);
+    arena.add(sums, (size_t)nb * 4);
+    arena.add(nodes, (size_t)max_nodes * sizeof(BNode));
+    arena.add(act_a, (size_t)max_active * 4);
+    arena.add(act_b, (size_t)max_active * 4);
+    arena.add(bins, (size_t)max_active * sizeof(Bins));
+    arena.add(split, (size_t)max_active * sizeof(Split));
+    arena.add(counters, 32);
+    arena.add(small_rec, (size_t)n * sizeof(Rec));
+    arena.add(small_nodes, (size_t)n * 2 * sizeof(pt_bvh_node));
+    arena.add(small_list, (size_t)max_active * 4);
+    arena.add(small_level, (size_t)max_active * 4);
+    arena.add(small_splits, (size_t)max_nodes * 4);
+    arena.add(splits, (size_t)max_nodes * 4);  // (the level nodes are at most max_nodes)
+    arena.add(event, (size_t)max_nodes * 4);
+    arena.add(newid, (size_t)max_nodes * 4);
+    BUILD_HIP(arena.commit());
+    BUILD_HIP(final_idx.alloc((size_t)n * 4));  // becomes the tree's index array
     BUILD_HIP(hipMemsetAsync(small_splits.p, 0, (size_t)max_nodes * 4, st));
     uint32_t h_cnt[8] = {1, 0, 0, 0, 0, 0, 0, 0};  // nodes, next active, hazard, -, small roots, deepest level below a small root
     BUILD_HIP(hipMemcpyAsync(counters.p, h_cnt, 32, hipMemcpyHostToDevice, st));
@@ -956,7 +1001,8 @@ int build_bvh_device(int prim_kind, const float* d_geom, uint32_t n, DeviceTree&
     tick("alloc, records, root");
     std::vector<uint32_t> level_start{0, 1};  // node ids of level L are [level_start[L], level_start[L + 1])
     // Subtrees of at most kSmall primitives are finished by one wave each (k_small_wave).  Measured with limits of 16 / 32 /
-    // 64 / 128 / 256 / 512: 10 M triangles 85 / 74 / 62 / 54 / 60 / 100 ms, 871 k triangles 12.8 / 11.9 / 10.7 / 9.8 / 11.0 / 15.3 ms.
+    // 64 / 128 / 256 / 512: 10 M triangles 85 / 74 / 62 / 54 / 60 / 100 ms, 871 k triangles 12.8 / 11.9 / 10.7 / 9.8 / 11.0 / 15.3 ms
+    // (with the first wave kernel; the present one: 128 -> 41 ms, 256 -> 48 ms).
     const uint32_t small_limit = kSmall;
     uint32_t n_active = n > small_limit ? 1 : 0;
     Buf *rc = &rec_a, *rn = &rec_b, *sc = &seg_a, *sn = &seg_b, *ac = &act_a, *an = &act_b;
@@ -1009,9 +1055,6 @@ int build_bvh_device(int prim_kind, const float* d_geom, uint32_t n, DeviceTree&
         hipLaunchKernelGGL(k_small_wave, dim3(n_small), dim3(64), 0, st, small_list.as<uint32_t>(), small_level.as<uint32_t>(), n_small, nodes.as<BNode>(),
                            small_rec.as<Rec>(), small_nodes.as<pt_bvh_node>(), small_splits.as<uint32_t>(), final_idx.as<uint32_t>(), counters.as<uint32_t>());
 
-    BUILD_HIP(splits.alloc((size_t)n_level_nodes * 4));
-    BUILD_HIP(event.alloc((size_t)n_level_nodes * 4));
-    BUILD_HIP(newid.alloc((size_t)n_level_nodes * 4));
     BUILD_HIP(hipMemsetAsync(event.p, 0, 4, st));  // the root: split event 0, node 0
     BUILD_HIP(hipMemsetAsync(newid.p, 0, 4, st));
     for (uint32_t L = levels; L-- > 0;)
@@ -1047,12 +1090,14 @@ int build_bvh_device(int prim_kind, const float* d_geom, uint32_t n, DeviceTree&
 int flatten_bvh_device(const DeviceTree& t, uint32_t big_from, DeviceFlat& out, hipStream_t st, std::string* err) {
     const uint32_t nn = t.n_nodes;
     Buf internal, big, pair_of, big_of, sums, root_ref, pairs, big_leaf;
-    BUILD_HIP(internal.alloc((size_t)nn * 4));
-    BUILD_HIP(big.alloc((size_t)nn * 4));
-    BUILD_HIP(pair_of.alloc(((size_t)nn + 1) * 4));
-    BUILD_HIP(big_of.alloc(((size_t)nn + 1) * 4));
-    BUILD_HIP(sums.alloc(((size_t)(nn + kScanTile - 1) / kScanTile) * 4));
-    BUILD_HIP(root_ref.alloc(4));
+    Arena arena;
+    arena.add(internal, (size_t)nn * 4);
+    arena.add(big, (size_t)nn * 4);
+    arena.add(pair_of, ((size_t)nn + 1) * 4);
+    arena.add(big_of, ((size_t)nn + 1) * 4);
+    arena.add(sums, ((size_t)(nn + kScanTile - 1) / kScanTile) * 4);
+    arena.add(root_ref, 4);
+    BUILD_HIP(arena.commit());
     hipLaunchKernelGGL(k_node_flags, dim3(blocks(nn)), dim3(kBlock), 0, st, (const pt_bvh_node*)t.nodes, nn, big_from, internal.as<uint32_t>(), big.as<uint32_t>());
     scan_flags(internal.as<uint32_t>(), nn, sums.as<uint32_t>(), pair_of.as<uint32_t>(), st);
     scan_flags(big.as<uint32_t>(), nn, sums.as<uint32_t>(), big_of.as<uint32_t>(), st);
