@@ -511,13 +511,17 @@ static int finalize_scene(pt_ctx* c) {
         if (dbg) std::fprintf(stderr, "[ptcore] finalize: %-26s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
         t_last = now;
     };
-    for (uint64_t i = 0; i < n; ++i)
-        if (c->mat_id[i] >= c->mats.size()) return c->fail(PT_ERR_INVALID, "pt_build: material id out of range");
-
-    // lights list, bvh.rs:29-35
+    // material ids in range; lights list, bvh.rs:29-35 (one pass over the ids: 10 M of them are a few milliseconds)
+    std::vector<uint8_t> emissive(c->mats.size());
+    for (size_t m = 0; m < c->mats.size(); ++m) emissive[m] = c->mats[m].kind == PT_MAT_EMISSIVE;
     c->bvh.lights.clear();
-    for (uint64_t i = 0; i < n; ++i)
-        if (c->mats[c->mat_id[i]].kind == PT_MAT_EMISSIVE) c->bvh.lights.push_back((uint32_t)i);
+    const uint32_t n_mats = (uint32_t)c->mats.size();
+    const uint32_t* ids = c->mat_id.data();
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint32_t id = ids[i];
+        if (id >= n_mats) return c->fail(PT_ERR_INVALID, "pt_build: material id out of range");
+        if (emissive[id]) c->bvh.lights.push_back((uint32_t)i);
+    }
     bool neg_nee = false;
     for (const pt_material& m : c->mats)
         if (m.kind == PT_MAT_DIFFUSE && std::fmin(1.0f - m.a, 0.0f) != 0.0f) neg_nee = true;
