@@ -60,6 +60,29 @@ def test_product_does_not_reference_oracle():
     assert not bad, bad
 
 
+def test_header_is_plain_c(tmp_path):
+    """include/ptcore.h is the boundary a C, cgo or bindgen caller sees: it must compile as strict C99 on its own,
+    and the structs that cross it keep the sizes the bindings (bindings/rust/ptcore-sys, pathtracer_amd/ptcore.py) assume."""
+    import os
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('''#include "ptcore.h"
+#include <stdio.h>
+int main(void) {
+    printf("%u %u %u %u %u\\n", (unsigned)sizeof(pt_ray), (unsigned)sizeof(pt_hit), (unsigned)sizeof(pt_bvh_node),
+           (unsigned)sizeof(pt_material), (unsigned)sizeof(pt_shard));
+    return 0;
+}
+''')
+    exe = str(tmp_path / "abi")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", exe], check=True)
+    sizes = [int(x) for x in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
+    import ctypes
+    from pathtracer_amd import ptcore as pc, scenes
+    assert sizes == [28, pc.HIT_DTYPE.itemsize, pc.NODE_DTYPE.itemsize, scenes.MATERIAL_DTYPE.itemsize, ctypes.sizeof(pc.Shard)]
+
+
 def test_fastdiv_is_exact(tmp_path):
     """pt_pixelmap.h FastDiv: floor(n / d) for n < 2^31 as multiply-high + shift (the slot -> pixel mapping of the kernels
     and of pt_shard_map).  Every d up to 5000, powers of two and their neighbours, random d; n at 0, around multiples
