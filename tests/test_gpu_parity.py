@@ -1171,11 +1171,14 @@ def test_bench_two_ranks_rehearsed_on_one_gpu(shard):
     assert round(out["mpaths_per_s"] * out["ms_per_step"] * 2 * 1e3) == pytest.approx(paths, rel=1e-6)
 
 
-def test_handle_input_through_the_cpp_host(orc, sky, tmp_path):
+@pytest.mark.parametrize("scene_kind", ["obj", "cube"])
+def test_handle_input_through_the_cpp_host(orc, sky, tmp_path, scene_kind):
     """Camera::handle_input (camera.rs:114-212) end to end in the C++ host mirror: key sets -> origin / target ->
     Camera::update on the device (autofocus included).  `render --keys` prints the pose after every step; the
     oracle's update() on the same origin / target (restated from camera.rs by tests/test_host_input_cpu.py) must
-    give the same basis, screen corners and focal distance bit for bit."""
+    give the same basis, screen corners and focal distance bit for bit.  Two scenes: a mesh that reaches both hosts
+    through one OBJ file, and the C++ host's own `--cube`, which must be BASELINE C2's cube (scenes.glass_cube_scene)
+    to the last bit of every corner — round 2 had it one ulp off (0.7f - 0.3f), which moved p1 after keys Q, D, F."""
     import subprocess
     from test_host_input_cpu import reference_handle_input
     render = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pathtracer_amd", "host", "render")
@@ -1183,23 +1186,28 @@ def test_handle_input_through_the_cpp_host(orc, sky, tmp_path):
     sky_file = str(tmp_path / "sky.raw")
     np.ascontiguousarray(sky, np.float32).tofile(sky_file)
     W, H = 64, 48
-    # the scene goes through an OBJ file so that both sides hold the very same float32 vertices
-    from pathtracer_amd import mesh
-    pos, nrm, _, _ = scenes.statue_scene(40, 25, 8, 3)
-    obj = str(tmp_path / "statue.obj")
-    with open(obj, "w") as f:
-        for t in range(len(pos) - 3):
-            for k in range(3):
-                f.write("v %.9g %.9g %.9g\n" % tuple(pos[t, 3 * k:3 * k + 3]))
-                f.write("vn %.9g %.9g %.9g\n" % tuple(nrm[t, 3 * k:3 * k + 3]))
-            f.write("f %d//%d %d//%d %d//%d\n" % (3 * t + 1, 3 * t + 1, 3 * t + 2, 3 * t + 2, 3 * t + 3, 3 * t + 3))
-    r = subprocess.run([render, "--obj", obj, "--sky", sky_file, "--size", f"{W}x{H}", "--frames", "1", "--out", str(tmp_path / "f.ppm"),
+    if scene_kind == "cube":
+        scene_args = ["--cube"]
+        o = orc.from_scene(scenes.glass_cube_scene(), sky)
+    else:
+        # the scene goes through an OBJ file so that both sides hold the very same float32 vertices
+        from pathtracer_amd import mesh
+        pos, nrm, _, _ = scenes.statue_scene(40, 25, 8, 3)
+        obj = str(tmp_path / "statue.obj")
+        with open(obj, "w") as f:
+            for t in range(len(pos) - 3):
+                for k in range(3):
+                    f.write("v %.9g %.9g %.9g\n" % tuple(pos[t, 3 * k:3 * k + 3]))
+                    f.write("vn %.9g %.9g %.9g\n" % tuple(nrm[t, 3 * k:3 * k + 3]))
+                f.write("f %d//%d %d//%d %d//%d\n" % (3 * t + 1, 3 * t + 1, 3 * t + 2, 3 * t + 2, 3 * t + 3, 3 * t + 3))
+        scene_args = ["--obj", obj]
+        p2, n2, m2, rows = mesh.load_mesh(obj, scenes.GLASS_BLUE)
+        o = orc.from_scene(scenes.wrap_mesh(p2, n2, m2, rows, floor_speculaty=0.5), sky)
+    r = subprocess.run([render, *scene_args, "--sky", sky_file, "--size", f"{W}x{H}", "--frames", "1", "--out", str(tmp_path / "f.ppm"),
                         "--keys", ";".join(",".join(k) if k else "-" for k in steps)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     poses = [ln.split()[1:] for ln in r.stdout.splitlines() if ln.startswith("pose ")]
     assert len(poses) == len(steps)
-    p2, n2, m2, rows = mesh.load_mesh(obj, scenes.GLASS_BLUE)
-    o = orc.from_scene(scenes.wrap_mesh(p2, n2, m2, rows, floor_speculaty=0.5), sky)
     origin, target = np.array(scenes.CAMERA_ORIGIN, np.float32), np.array(scenes.CAMERA_TARGET, np.float32)
     o.set_camera(origin, target, W, H)
     cam = o.camera()
