@@ -112,6 +112,8 @@ pub struct pt_counters {
     pub tail_ms: f64,
     pub extend_ms_sum: f64,
     pub tail_ms_sum: f64,
+    pub redo_paths: u64,
+    pub redo_restarts: u64,
 }
 
 extern "C" {

@@ -110,6 +110,11 @@ typedef struct pt_counters {
     /* plain sums of the same launch durations (= a profiler's average duration x launches); they exceed
      * extend_ms / tail_ms exactly when launches overlapped (several batches or calls in flight) */
     double extend_ms_sum, tail_ms_sum;
+    /* The NEE block of src/camera.rs:314-338 where the fast kernels leave it out (its weight is exactly 0 there) and it could
+     * still change a sum (a transport too large, infinite or NaN for 0 * product to be 0): redo_paths = paths finished by the
+     * second, literal pass since the last reset; redo_restarts = batches run again as a whole with the NEE kernels because
+     * more paths asked than PT_OPT_REDO_CAPACITY (the ray counters then include the abandoned attempt). */
+    uint64_t redo_paths, redo_restarts;
 } pt_counters;
 
 /* flags for pt_render */
@@ -231,7 +236,8 @@ int pt_shard_unpack(pt_ctx *ctx, const pt_shard *shard, const float *slab_dev, u
 /* BVH::intersect_closest / intersect_any (src/bvh.rs:180-271) over a batch of rays. */
 int pt_trace(pt_ctx *ctx, const pt_ray *rays, uint64_t n, int any_hit, pt_hit *hits);
 /* pt_trace without any allocation.  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot
- * call hipMalloc — code under HIP graph capture, tight serving loops, harnesses that forbid allocation.
+ * call hipMalloc — tight serving loops, harnesses that forbid allocation.  (It is NOT for a stream under HIP graph
+ * capture: like pt_trace it copies rays from and hits to the caller's host memory and waits for the stream.)
  * Same arguments, results and counters as pt_trace; the device copies of rays / hits and the overflow of the
  * per-lane traversal stacks live in a static device array (8.6 MiB per GPU, held until the process ends)
  * instead of per-call buffers.  Limits: n <= 16384 rays per call and a tree of at most 76 levels
@@ -260,9 +266,11 @@ int pt_sample_skybox(pt_ctx *ctx, const float *dirs, uint64_t n, float *rgb);
  *  PT_OPT_MERGE_QUEUED_CALLS  a pt_render_async call that continues the newest queued call (same frame, depth, seed,
  *                         shard and flags, the next sample indices) while that call has not started yet is added to it, up
  *                         to this many paths per merged call (default 128 Mi; 0 = never merge).  Same results, fewer and
- *                         larger launches when calls arrive faster than they are rendered */
+ *                         larger launches when calls arrive faster than they are rendered
+ *  PT_OPT_REDO_CAPACITY  paths per batch that may ask for the literal NEE block before the whole batch is run again with the
+ *                         NEE kernels (default 65536; tests set it to 0 to exercise the restart) */
 enum { PT_OPT_BATCH_PATHS = 0, PT_OPT_LANES = 1, PT_OPT_TAIL_MIN_PATHS = 2, PT_OPT_TAIL_FRACTION = 3,
-       PT_OPT_TAIL_STREAMS = 4, PT_OPT_TAIL_PATHS_PER_LANE = 5, PT_OPT_SIMPLE_EXTEND = 6, PT_OPT_BULK_STREAMS = 7, PT_OPT_TAIL_MODE = 8, PT_OPT_FIRST_CHECK_ROUND = 9, PT_OPT_RENDER_MODE = 10, PT_OPT_MERGE_QUEUED_CALLS = 11, PT_OPT_DEVICE_BUILD = 12 };
+       PT_OPT_TAIL_STREAMS = 4, PT_OPT_TAIL_PATHS_PER_LANE = 5, PT_OPT_SIMPLE_EXTEND = 6, PT_OPT_BULK_STREAMS = 7, PT_OPT_TAIL_MODE = 8, PT_OPT_FIRST_CHECK_ROUND = 9, PT_OPT_RENDER_MODE = 10, PT_OPT_MERGE_QUEUED_CALLS = 11, PT_OPT_DEVICE_BUILD = 12, PT_OPT_REDO_CAPACITY = 13 };
 int pt_set_option(pt_ctx *ctx, int option, uint64_t value);
 int pt_get_counters(pt_ctx *ctx, pt_counters *out);
 /* Diagnostics of the wavefront loop (no counterpart in the reference): after a pt_render with

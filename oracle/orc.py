@@ -46,7 +46,8 @@ class Counters(C.Structure):
                 ("node_tests", C.c_uint64), ("prim_tests", C.c_uint64), ("extend_launches", C.c_uint64),
                 ("extend_ms", C.c_double), ("render_ms", C.c_double), ("tail_rays", C.c_uint64),
                 ("tail_node_tests", C.c_uint64), ("tail_prim_tests", C.c_uint64), ("tail_launches", C.c_uint64),
-                ("tail_ms", C.c_double), ("extend_ms_sum", C.c_double), ("tail_ms_sum", C.c_double)]
+                ("tail_ms", C.c_double), ("extend_ms_sum", C.c_double), ("tail_ms_sum", C.c_double),
+                ("redo_paths", C.c_uint64), ("redo_restarts", C.c_uint64)]   # pt_counters of include/ptcore.h, 136 bytes
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

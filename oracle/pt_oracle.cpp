@@ -281,6 +281,9 @@ struct orc_ctx {
     bool built = false;
     bool hazard = false;
     uint32_t max_depth = 0;
+    // nee_mode 1 (the device's rule for leaving the NEE block out), set by nee_rule() after build()
+    float nee_thr = 3.402823466e38f;
+    bool nee_literal = false;
 
     // camera (camera.rs:18-37)
     V3 origin{}, target{}, direction{}, p1{}, p2{}, p3{}, up{}, right{};
@@ -462,6 +465,7 @@ struct orc_ctx {
             size_t ni = stack.back();
             stack.pop_back();
             if (nodes[ni].count > 2 && partition(ni)) {
+                if (hazard) return PT_ERR_BVH;  // SURVEY 3.5 "Hazard": the reference would split the full child for ever
                 size_t left = nodes[ni].left_first;
                 depth_of.resize(nodes.size());
                 depth_of[left] = depth_of[left + 1] = depth_of[ni] + 1;
@@ -629,10 +633,40 @@ struct orc_ctx {
         return Ray{org, dir, INF};
     }
 
+    // The device's rule for nee_mode 1, restated: the NEE block (camera.rs:314-338) adds weight * X with weight =
+    // min(1 - speculaty, 0).  Where the weight is 0 it adds +-0 — unless X is not finite (0 * inf = NaN).  X = transport *
+    // (cos_i / mis) * (light colour * brdf); cos_i / mis <= pi when both pdfs are >= 0, so X is finite while |transport| <=
+    // FLT_MAX / (3.25 * lcb), lcb = the largest |light colour * diffuse colour / pi| of the scene.  Lights whose area is not
+    // a finite number >= 0, or an lcb that is not finite, make every block run (nee_literal).
+    void nee_rule() {
+        nee_literal = false;
+        float lcb = 0.0f;
+        for (const pt_material& e : mats) {
+            if (e.kind != PT_MAT_EMISSIVE) continue;
+            for (const pt_material& d : mats) {
+                if (d.kind != PT_MAT_DIFFUSE) continue;
+                for (int ch = 0; ch < 3; ++ch) {
+                    float v = std::fabs(e.rgb[ch] * (FRAC_1_PI * d.rgb[ch]));
+                    if (!(v <= 3.402823466e38f)) nee_literal = true;
+                    else lcb = std::max(lcb, v);
+                }
+            }
+        }
+        double t = lcb > 0.0f ? 3.4028234663852886e38 / (3.25 * (double)lcb) : 3.4028234663852886e38;
+        nee_thr = t >= 3.4028234663852886e38 ? 3.402823466e38f : (float)t;
+        for (uint64_t l : lights) {
+            float a = prim_area(l);
+            if (!(a >= 0.0f && a <= 3.402823466e38f)) nee_literal = true;
+        }
+    }
+
     // ---- camera.rs:295-423
-    // nee_mode 0: literal (NEE block runs whenever the scene has a light)
-    // nee_mode 1: run it only when its weight min(1-speculaty, 0) is non-zero; identical image,
-    //             fewer any-hit rays (what the device path does)
+    // nee_mode 0: literal (the NEE block runs whenever the scene has a light), camera.rs:314-338 as written
+    // nee_mode 1: the device's rule — the block runs where its weight is non-zero, where the transport is beyond nee_thr
+    //             (inf and NaN included) and everywhere in a nee_literal scene; same sums as mode 0 (see nee_rule),
+    //             fewer any-hit rays
+    // nee_mode 2: round 2's rule, kept as the negative control of tests/test_nee_rule_cpu.py — the block runs only where its
+    //             weight is non-zero; differs from the reference where a transport is not finite
     V3 sample(Ray& ray, uint32_t depth, const RngKey& k, int nee_mode, Counters& c, std::vector<uint32_t>& st) const {
         V3 acc = v3(0, 0, 0);
         V3 transport = v3(1, 1, 1);
@@ -654,7 +688,8 @@ struct orc_ctx {
                 float speculaty = m.a;
                 if (inside) break;
                 float nee_w = fmin_(1.0f - speculaty, 0.0f);
-                if (!lights.empty() && (nee_mode == 0 || nee_w != 0.0f)) {
+                bool beyond = !(std::fabs(transport.x) <= nee_thr && std::fabs(transport.y) <= nee_thr && std::fabs(transport.z) <= nee_thr);
+                if (!lights.empty() && (nee_mode == 0 || nee_w != 0.0f || (nee_mode == 1 && (nee_literal || beyond)))) {
                     U4 rn = philox4x32_10(k.k0, k.k1, k.pixel, k.sample, 1 + it, 1);
                     // bvh.rs:273-284: Range::new(0, light_count).ind_sample() — rand 0.3.15 rejects draws at or above
                     // the largest multiple of the range (`zone`) and returns low + v % range.  The generator is the
@@ -792,7 +827,11 @@ int orc_set_sky(orc_ctx* c, const float* rgb, uint32_t w, uint32_t h) {
     c->sky_h = h;
     return 0;
 }
-int orc_build(orc_ctx* c) { return c->build(); }
+int orc_build(orc_ctx* c) {
+    int rc = c->build();
+    if (rc == PT_OK) c->nee_rule();
+    return rc;
+}
 int orc_bvh_sizes(orc_ctx* c, uint64_t* n_nodes, uint64_t* n_indices, uint32_t* max_depth) {
     *n_nodes = c->nodes.size();
     *n_indices = c->indices.size();

@@ -47,6 +47,7 @@ constexpr uint64_t kMergeSlots = 128ull << 20;  // queued calls are merged up to
 constexpr uint32_t kMaxLanes = 8;              // batches in flight (one HIP stream + path-state set each)
 constexpr uint64_t kTailMinPaths = 65536;      // hand a batch to the fused tail kernel below this many live paths ...
 constexpr uint64_t kTailFraction = 16;         // ... or below 1/16 of the batch
+constexpr uint64_t kRedoCap = 65536;           // paths per batch that may ask for the NEE block in a scene whose kernels leave it out
 
 // ---- pt_trace_noalloc: everything pt_trace allocates per call lives in one static device array instead.
 // Layout: [rays: kNoAllocMaxRays x pt_ray][hits: kNoAllocMaxRays x pt_hit][stack spill: levels x lanes x 8 B].
@@ -66,7 +67,9 @@ struct RenderLane {
     hipStream_t stream = nullptr;
     hipEvent_t ev_check = nullptr, ev_done = nullptr;
     uint32_t* h_qn = nullptr;  // pinned read-back word
-    DevBuf d_ro, d_rd, d_hit, d_tp, d_out, d_acc, d_pxs, d_q0, d_q1, d_qn, d_spill;
+    DevBuf d_ro, d_rd, d_hit, d_tp, d_out, d_acc, d_pxs, d_q0, d_q1, d_qn, d_spill, d_redo;
+    bool nee = false;          // the batch in flight runs the kernels with the NEE code (the scene needs them, or a restart after
+                               // more paths asked for the block than the redo list holds)
     PathState ps{};
     LaunchCfg cfg{};
     uint64_t cap_slots = 0;
@@ -118,7 +121,11 @@ struct pt_sched {
     uint64_t next_seq = 0;        // sequence number the next submitted batch gets
     uint64_t acc_seq = 0;         // sequence number of the next batch to be added to the accumulator
     hipEvent_t ev_epoch = nullptr;  // time zero of the timed intervals below
-    std::vector<std::pair<float, float>> ext_iv, tail_iv;  // [begin, end) in ms since ev_epoch
+    // [begin, end) in ms since ev_epoch of the timed launches that may still overlap one to come; whenever the queue runs
+    // empty their union is added to *_union_done, the lists are cleared and the epoch is dropped (the next timed call sets a
+    // new one), so neither the lists nor the offsets grow with the life of the context
+    std::vector<std::pair<double, double>> ext_iv, tail_iv;
+    double ext_union_done = 0, tail_union_done = 0;
     double ext_sum = 0, tail_sum = 0;
 };
 
@@ -154,7 +161,8 @@ struct pt_ctx {
     DevBuf d_stage_in, d_stage_out;  // device copies of the seams' inputs / outputs (pt_trace, pt_generate, pt_sample_skybox); grow only
     float spp = 0.f;          // samples submitted (what the frame holds once everything queued has been added)
     float spp_added = 0.f;    // samples whose k_accumulate has been enqueued on the accumulate stream so far
-    uint32_t samples_done = 0;
+    uint32_t samples_done = 0;      // global index the next shard-less call starts at (samples submitted)
+    uint32_t samples_added_end = 0; // ... and the one behind the last batch whose accumulate has been enqueued
 
     // pipeline
     LaunchCfg cfg{};          // grid geometry; every lane has its own spill area
@@ -178,6 +186,8 @@ struct pt_ctx {
     uint64_t opt_device_build = 1;  // pt_build builds the tree on the GPU (pt_build.hip) when the input allows it
     bool build_on_device = false;   // what the last pt_build did
     double build_ms = 0;            // ... and how long the tree build itself took (without flattening / upload)
+    uint64_t opt_redo_cap = kRedoCap;
+    uint64_t redo_paths = 0, redo_restarts = 0;  // paths finished by k_redo / batches run again with the NEE kernels, since the last reset
     uint64_t merged_calls = 0;  // pt_render_async calls that were added to a queued call instead of becoming a launch of their own
     std::vector<uint32_t> round_sizes;  // queue length of every round of the last finished batch
 
@@ -300,7 +310,7 @@ void pt_destroy(pt_ctx* c) {
     if (c->h_rgb) (void)hipHostFree(c->h_rgb);
     c->dtree.release();
     for (RenderLane& L : c->lanes) {
-        DevBuf* lb[] = {&L.d_ro, &L.d_rd, &L.d_hit, &L.d_tp, &L.d_out, &L.d_acc, &L.d_pxs, &L.d_q0, &L.d_q1, &L.d_qn, &L.d_spill};
+        DevBuf* lb[] = {&L.d_ro, &L.d_rd, &L.d_hit, &L.d_tp, &L.d_out, &L.d_acc, &L.d_pxs, &L.d_q0, &L.d_q1, &L.d_qn, &L.d_spill, &L.d_redo};
         for (DevBuf* b : lb) b->release();
         if (L.h_qn) (void)hipHostFree(L.h_qn);
         if (L.ev_check) (void)hipEventDestroy(L.ev_check);
@@ -395,16 +405,25 @@ int pt_build(pt_ctx* c) {
     if (c->opt_device_build) {  // same tree either way
         const auto t0 = std::chrono::steady_clock::now();
         std::string why;
-        if (int rc = build_bvh_device(c->prim_kind == PRIM_TRIANGLE ? 0 : 1, (const float*)c->d_raw_a.p, (uint32_t)n, c->dtree, c->stream, &why))
+        const int rc = build_bvh_device(c->prim_kind == PRIM_TRIANGLE ? 0 : 1, (const float*)c->d_raw_a.p, (uint32_t)n, c->dtree, c->stream, &why);
+        if (rc == PT_ERR_HIP) {
+            // the device build could not run (its temporaries are ~600 B per primitive: out of memory, typically): the host
+            // build below gives the same tree; pt_get_build_info says which one ran
+            (void)hipGetLastError();
+            c->dtree.release();
+            if (dbg) std::fprintf(stderr, "[ptcore] pt_build: device build failed (%s), building on the host\n", why.c_str());
+        } else if (rc) {
             return c->fail(rc, why);
-        c->build_on_device = true;
-        c->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        tick("tree (device)", t0);
-        c->host_bvh_current = false;
-        c->bvh.nodes.clear();
-        c->bvh.indices.clear();
-        c->bvh.max_depth = c->dtree.max_depth;
-        c->bvh.hazard = c->dtree.hazard;
+        } else {
+            c->build_on_device = true;
+            c->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            tick("tree (device)", t0);
+            c->host_bvh_current = false;
+            c->bvh.nodes.clear();
+            c->bvh.indices.clear();
+            c->bvh.max_depth = c->dtree.max_depth;
+            c->bvh.hazard = c->dtree.hazard;
+        }
     }
     if (!c->build_on_device) {
         const auto t0 = std::chrono::steady_clock::now();
@@ -526,6 +545,30 @@ static int finalize_scene(pt_ctx* c) {
     for (const pt_material& m : c->mats)
         if (m.kind == PT_MAT_DIFFUSE && std::fmin(1.0f - m.a, 0.0f) != 0.0f) neg_nee = true;
     c->nee = neg_nee && !c->bvh.lights.empty();
+#ifdef PT_FORCE_NEE
+    c->nee = !c->bvh.lights.empty();  // A/B: what the NEE code costs when it is compiled in and never runs (C3: -7.5 %)
+#endif
+    // Up to which |transport| the NEE block may be left out where its weight is 0 (shade_core has the argument): the block's
+    // product is transport * (cos / mis <= pi) * (light colour * brdf), so with lcb = the largest |light colour * colour / pi|
+    // over every emissive x diffuse material pair it stays finite for |transport| <= FLT_MAX / (3.25 * lcb).  A scene with a
+    // product that is not finite (here) or a light whose area is not a finite number >= 0 (k_light_check below) always runs it.
+    bool literal = false;
+    float lcb = 0.0f;
+    for (const pt_material& e : c->mats) {
+        if (e.kind != PT_MAT_EMISSIVE) continue;
+        for (const pt_material& d : c->mats) {
+            if (d.kind != PT_MAT_DIFFUSE) continue;
+            for (int ch = 0; ch < 3; ++ch) {
+                const float v = std::fabs(e.rgb[ch] * (kFrac1Pi * d.rgb[ch]));
+                if (!(v <= 3.402823466e38f)) literal = true;
+                else lcb = std::max(lcb, v);
+            }
+        }
+    }
+    {
+        const double t = lcb > 0.0f ? 3.4028234663852886e38 / (3.25 * (double)lcb) : 3.4028234663852886e38;
+        c->ds.nee_thr = t >= 3.4028234663852886e38 ? 3.402823466e38f : (float)t;
+    }
 
     // triangle leaves of kCoopLeafFrom primitives or more are marked for wave-cooperative testing (step_prim_wave);
     // sphere leaves stay sequential (Sphere::intersect compares with ray.distance), so only the > 31 escape applies
@@ -612,6 +655,19 @@ static int finalize_scene(pt_ctx* c) {
         S.root_min[a] = root_min[a];
         S.root_max[a] = root_max[a];
     }
+    if (S.n_lights != 0) {
+        ScopedBuf d_flag;
+        if ((rc = dev_alloc(c, d_flag, 16))) return rc;
+        PT_HIP(c, hipMemsetAsync(d_flag.p, 0, 16, c->stream));
+        launch_light_check(c->prim_kind, S, (uint32_t*)d_flag.p, c->stream);
+        PT_HIP(c, hipGetLastError());
+        uint32_t bad_area = 0;
+        PT_HIP(c, hipMemcpyAsync(&bad_area, d_flag.p, 4, hipMemcpyDeviceToHost, c->stream));
+        PT_HIP(c, hipStreamSynchronize(c->stream));
+        if (bad_area) literal = true;
+    }
+    S.nee_literal = literal && S.n_lights != 0 ? 1u : 0u;
+    if (S.nee_literal) c->nee = true;  // such a scene runs the kernels with the NEE code throughout
     // overflow area of the LDS stacks: exactly the levels the tree can need beyond kLdsStack
     const uint32_t extra = S.stack_cap > (uint32_t)kLdsStack ? S.stack_cap - kLdsStack : 0;
     c->spill_bytes = (size_t)std::max(extra, 1u) * c->cfg.spill_stride * sizeof(unsigned long long);
@@ -705,7 +761,7 @@ int pt_reset_accum(pt_ctx* c) {
     PT_HIP(c, hipMemsetAsync(c->d_accum.p, 0, (size_t)c->cam.width * c->cam.height * 3 * sizeof(float), c->stream));
     PT_HIP(c, hipStreamSynchronize(c->stream));
     c->spp = c->spp_added = 0.f;
-    c->samples_done = 0;
+    c->samples_done = c->samples_added_end = 0;
     return PT_OK;
 }
 
@@ -818,7 +874,7 @@ static int lane_alloc(pt_ctx* c, RenderLane& L, uint64_t slots, uint32_t rounds)
         if ((rc = dev_alloc(c, L.d_q1, slots * 4))) return rc;
         L.cap_slots = slots;
     }
-    if (c->opt_render_mode != 1 && c->nee && L.d_acc.bytes < slots * 16)
+    if (c->opt_render_mode != 1 && L.nee && L.d_acc.bytes < slots * 16)
         if ((rc = dev_alloc(c, L.d_acc, slots * 16))) return rc;
     if (rounds + 2 > L.qn_len) {  // queue lengths [0, rounds+2) then one fetch cursor per round
         if ((rc = dev_alloc(c, L.d_qn, (size_t)(rounds + 2) * 8 + 64))) return rc;  // + 8 region cursors of k_path
@@ -826,6 +882,10 @@ static int lane_alloc(pt_ctx* c, RenderLane& L, uint64_t slots, uint32_t rounds)
     }
     if (!L.d_spill.p || L.d_spill.bytes < c->spill_bytes)
         if ((rc = dev_alloc(c, L.d_spill, c->spill_bytes))) return rc;
+    if ((rc = dev_alloc(c, L.d_redo, std::max<uint64_t>(c->opt_redo_cap, 1) * 4))) return rc;
+    L.ps.redo.list = (uint32_t*)L.d_redo.p;
+    L.ps.redo.count = (uint32_t*)L.d_qn.p + 2 * (rounds + 2) + 8;  // behind k_path's 8 region cursors; zeroed with them in lane_start
+    L.ps.redo.cap = (uint32_t)c->opt_redo_cap;
     L.ps.ro = (float4*)L.d_ro.p;
     L.ps.rd = (float4*)L.d_rd.p;
     L.ps.hit = (float4*)L.d_hit.p;
@@ -870,11 +930,12 @@ static int lane_issue_rounds(pt_ctx* c, RenderLane& L, RenderJob& J, uint32_t up
         launch_extend(c->prim_kind, J.count, c->opt_simple_extend != 0, c->ds, L.ps, q[r & 1], qn + r, qn + J.rounds + 2 + r, L.cfg, counters, L.stream);
         if ((rc = timed_end(c, J, J.ext_events, L.stream))) return rc;
         c->extend_launches += 1;
-        launch_shade(c->prim_kind, c->nee, c->ds, L.ps, J.M, q[r & 1], qn + r, q[(r + 1) & 1], qn + r + 1, J.max_depth, L.sample_base,
+        launch_shade(c->prim_kind, L.nee, c->ds, L.ps, J.M, q[r & 1], qn + r, q[(r + 1) & 1], qn + r + 1, J.max_depth, L.sample_base,
                      J.k0, J.k1, L.cfg, counters, L.stream);
     }
     L.round = upto;
     PT_HIP(c, hipMemcpyAsync(L.h_qn, qn + upto, 4, hipMemcpyDeviceToHost, L.stream));
+    PT_HIP(c, hipMemcpyAsync(L.h_qn + 1, L.ps.redo.count, 4, hipMemcpyDeviceToHost, L.stream));
     PT_HIP(c, hipEventRecord(L.ev_check, L.stream));
     PT_HIP(c, hipGetLastError());
     return PT_OK;
@@ -888,14 +949,16 @@ static int lane_start(pt_ctx* c, RenderLane& L, RenderJob& J, uint32_t batch, ui
     L.sample_base = sample_base;
     L.round = 0;
     L.state = RenderLane::RUNNING;
+    L.h_qn[1] = 0;
     PT_HIP(c, hipMemsetAsync(qn, 0, (size_t)(J.rounds + 2) * 8 + 64, L.stream));
     if (c->opt_render_mode == 1) {
         // the whole batch in one persistent kernel (generate + sample, state in registers)
         if ((rc = timed_begin(c, J, J.tail_events, L.stream))) return rc;
-        launch_path(c->prim_kind, c->nee, J.count, c->ds, (const DevCamera*)c->d_cam.p, J.M, ns, sample_base, J.max_depth, J.k0, J.k1,
-                    L.ps.out, qn + 2 * (J.rounds + 2), L.cfg, (unsigned long long*)c->d_counters.p, L.stream);
+        launch_path(c->prim_kind, L.nee, J.count, c->ds, (const DevCamera*)c->d_cam.p, J.M, ns, sample_base, J.max_depth, J.k0, J.k1,
+                    L.ps.out, qn + 2 * (J.rounds + 2), L.ps.redo, L.cfg, (unsigned long long*)c->d_counters.p, L.stream);
         if ((rc = timed_end(c, J, J.tail_events, L.stream))) return rc;
         c->tail_launches += 1;
+        PT_HIP(c, hipMemcpyAsync(L.h_qn + 1, L.ps.redo.count, 4, hipMemcpyDeviceToHost, L.stream));
         PT_HIP(c, hipEventRecord(L.ev_check, L.stream));
         PT_HIP(c, hipGetLastError());
         L.round = J.rounds;
@@ -903,7 +966,7 @@ static int lane_start(pt_ctx* c, RenderLane& L, RenderJob& J, uint32_t batch, ui
         L.state = RenderLane::TAILING;  // ev_check now stands for the whole batch
         return PT_OK;
     }
-    launch_raygen((const DevCamera*)c->d_cam.p, J.M, L.ps, ns, sample_base, J.k0, J.k1, c->nee, (uint32_t*)L.d_q0.p, qn,
+    launch_raygen((const DevCamera*)c->d_cam.p, J.M, L.ps, ns, sample_base, J.k0, J.k1, L.nee, (uint32_t*)L.d_q0.p, qn,
                   (unsigned long long*)c->d_counters.p, L.stream);
     if (J.max_depth == 0)  // `for _ in 0..0` never runs: every sample is (0,0,0)
         PT_HIP(c, hipMemsetAsync(L.d_out.p, 0, (size_t)ns * J.M.npix_pad * 16, L.stream));
@@ -932,18 +995,19 @@ static int lane_tail(pt_ctx* c, RenderLane& L, RenderJob& J, uint32_t live) {
             launch_extend(c->prim_kind, J.count, c->opt_simple_extend != 0, c->ds, L.ps, q[r & 1], qn + r, qn + J.rounds + 2 + r, small, counters, ts);
             if ((rc = timed_end(c, J, J.ext_events, ts))) return rc;
             c->extend_launches += 1;
-            launch_shade(c->prim_kind, c->nee, c->ds, L.ps, J.M, q[r & 1], qn + r, q[(r + 1) & 1], qn + r + 1, J.max_depth, L.sample_base,
+            launch_shade(c->prim_kind, L.nee, c->ds, L.ps, J.M, q[r & 1], qn + r, q[(r + 1) & 1], qn + r + 1, J.max_depth, L.sample_base,
                          J.k0, J.k1, small, counters, ts);
         }
         L.round = J.rounds;
     } else if (live != 0 && L.round < J.rounds) {
         uint32_t* qn = (uint32_t*)L.d_qn.p;
         if ((rc = timed_begin(c, J, J.tail_events, ts))) return rc;
-        launch_tail(c->prim_kind, c->nee, J.count, (int)c->opt_tail_mode, c->ds, L.ps, (L.round & 1) ? (uint32_t*)L.d_q1.p : (uint32_t*)L.d_q0.p, qn + L.round,
+        launch_tail(c->prim_kind, L.nee, J.count, (int)c->opt_tail_mode, c->ds, L.ps, (L.round & 1) ? (uint32_t*)L.d_q1.p : (uint32_t*)L.d_q0.p, qn + L.round,
                     qn + 2 * J.rounds + 3, (uint32_t)((live + c->opt_tail_paths_per_lane - 1) / c->opt_tail_paths_per_lane), J.max_depth, J.k0, J.k1, L.cfg, (unsigned long long*)c->d_counters.p, ts);
         if ((rc = timed_end(c, J, J.tail_events, ts))) return rc;
         c->tail_launches += 1;
     }
+    PT_HIP(c, hipMemcpyAsync(L.h_qn + 1, L.ps.redo.count, 4, hipMemcpyDeviceToHost, ts));
     PT_HIP(c, hipEventRecord(L.ev_check, ts));
     PT_HIP(c, hipGetLastError());
     L.state = RenderLane::TAILING;
@@ -953,33 +1017,67 @@ static int lane_tail(pt_ctx* c, RenderLane& L, RenderJob& J, uint32_t live) {
 // All paths of the batch are finished: add its samples.  Every accumulate runs on the one
 // accumulate stream and the host enqueues them in batch order, so every pixel's sum is built in
 // sample order (main.rs:159 adds one frame at a time) across batches and across calls.
+static int lane_start(pt_ctx* c, RenderLane& L, RenderJob& J, uint32_t batch, uint32_t ns, uint32_t sample_base);
+static int lane_alloc(pt_ctx* c, RenderLane& L, uint64_t slots, uint32_t rounds);
+
+// On return the lane is DRAINING (accumulate enqueued) — or running its batch a second time (see below).
 static int lane_accumulate(pt_ctx* c, RenderLane& L, RenderJob& J) {
+    // Paths the kernels without the NEE code gave up (shade_core, SHADE_REDO) are finished first, on the accumulate stream
+    // right in front of the batch's accumulate.  Everything the batch launched has completed (the host saw its event),
+    // so the count read back behind the last kernel is final.
+    const uint32_t n_redo = L.nee ? 0u : L.h_qn[1];
+    if (n_redo > L.ps.redo.cap) {
+        // more than the list holds: the batch runs again from the start with the NEE kernels, which never give a path up
+        // (the frame is the same; the ray counters then include the abandoned attempt)
+        c->redo_restarts += 1;
+        L.nee = true;
+        int rc = lane_alloc(c, L, J.batch_slots, J.rounds);
+        if (rc) return rc;
+        return lane_start(c, L, J, L.batch, L.ns, L.sample_base);
+    }
+    if (n_redo) {
+        launch_redo(c->prim_kind, J.count, c->ds, (const DevCamera*)c->d_cam.p, J.M, L.ns, c->opt_render_mode == 1, L.sample_base, J.max_depth, J.k0,
+                    J.k1, L.ps.out, L.ps.redo.list, n_redo, L.cfg, (unsigned long long*)c->d_counters.p, c->acc_stream);
+        c->redo_paths += n_redo;
+    }
     launch_accumulate(J.M, L.ps.out, L.ns, c->opt_render_mode == 1, (float*)c->d_accum.p, c->acc_stream);
     PT_HIP(c, hipEventRecord(L.ev_done, c->acc_stream));
     PT_HIP(c, hipGetLastError());
     c->spp_added += (float)L.ns;
+    c->samples_added_end = L.sample_base + L.ns;
     L.state = RenderLane::DRAINING;
     return PT_OK;
 }
 
 // total length of the union of [begin, end) intervals
-static double union_ms(std::vector<std::pair<float, float>> iv) {
+static double union_ms(std::vector<std::pair<double, double>> iv) {
     std::sort(iv.begin(), iv.end());
     double total = 0;
-    float lo = 0, hi = 0;
+    double lo = 0, hi = 0;
     bool open = false;
     for (const auto& p : iv) {
         if (open && p.first <= hi) {
             hi = std::max(hi, p.second);
         } else {
-            if (open) total += (double)hi - lo;
+            if (open) total += hi - lo;
             lo = p.first;
             hi = p.second;
             open = true;
         }
     }
-    if (open) total += (double)hi - lo;
+    if (open) total += hi - lo;
     return total;
+}
+
+static void fold_intervals(pt_sched& S) {
+    S.ext_union_done += union_ms(S.ext_iv);
+    S.tail_union_done += union_ms(S.tail_iv);
+    S.ext_iv.clear();
+    S.tail_iv.clear();
+    if (S.ev_epoch) {
+        (void)hipEventDestroy(S.ev_epoch);
+        S.ev_epoch = nullptr;
+    }
 }
 
 // a finished job leaves the queue: its timed intervals are kept relative to the context's epoch event
@@ -993,7 +1091,7 @@ static int retire_job(pt_ctx* c, RenderJob& J) {
             PT_HIP(c, hipEventElapsedTime(&b, S.ev_epoch, ev[i]));
             PT_HIP(c, hipEventElapsedTime(&e, S.ev_epoch, ev[i + 1]));
             PT_HIP(c, hipEventElapsedTime(&d, ev[i], ev[i + 1]));
-            (which ? S.tail_iv : S.ext_iv).push_back({b, std::max(e, b)});
+            (which ? S.tail_iv : S.ext_iv).push_back({(double)b, (double)std::max(e, b)});
             (which ? S.tail_sum : S.ext_sum) += d;
         }
         destroy_events(ev);
@@ -1013,7 +1111,8 @@ static int abort_jobs(pt_ctx* c, int rc) {
     }
     S.jobs.clear();
     S.acc_seq = S.next_seq;
-    c->spp = c->spp_added;  // the frame holds what was added before the failure
+    c->spp = c->spp_added;  // the frame holds what was added before the failure ...
+    c->samples_done = c->samples_added_end;  // ... and the next shard-less call goes on behind its last sample, not behind the dropped ones
     for (RenderLane& L : c->lanes) {
         L.state = RenderLane::IDLE;
         L.job = nullptr;
@@ -1036,11 +1135,13 @@ static int pump_once(pt_ctx* c, bool& progressed) {
             for (RenderJob& cand : S.jobs)
                 if (cand.next_batch < cand.n_batches) { J = &cand; break; }
             if (!J || busy >= J->max_lanes) continue;
+            L.nee = c->nee;
             int rc = lane_alloc(c, L, J->batch_slots, J->rounds);
             if (rc) return rc;
             hipStream_t& bs = c->bulk_stream[i % c->opt_bulk_streams];
             if (!bs) PT_HIP(c, hipStreamCreateWithFlags(&bs, hipStreamNonBlocking));
             L.stream = bs;
+            L.nee = c->nee;
             L.job = J;
             L.seq = J->seq0 + J->next_batch;
             const uint64_t done = (uint64_t)J->next_batch * J->per_batch;
@@ -1078,7 +1179,7 @@ static int pump_once(pt_ctx* c, bool& progressed) {
         if (L.state == RenderLane::READY && L.seq == S.acc_seq) {
             int rc = lane_accumulate(c, L, J);
             if (rc) return rc;
-            S.acc_seq += 1;
+            if (L.state == RenderLane::DRAINING) S.acc_seq += 1;  // (otherwise the batch runs again with the NEE kernels)
             progressed = true;
         } else if (L.state == RenderLane::DRAINING) {
             hipError_t q = hipEventQuery(L.ev_done);
@@ -1100,6 +1201,7 @@ static int pump_once(pt_ctx* c, bool& progressed) {
         if (rc) return rc;
         S.jobs.pop_front();
         progressed = true;
+        if (S.jobs.empty()) fold_intervals(S);  // nothing in flight: no launch to come can overlap what has been timed
     }
     return PT_OK;
 }
@@ -1209,7 +1311,7 @@ int pt_render_async(pt_ctx* c, uint32_t spp, uint32_t max_depth, uint64_t seed, 
     if (M.npix_pad == 0) {  // this rank owns no tile
         c->spp += (float)spp;
         c->spp_added += (float)spp;
-        c->samples_done = sample_begin + spp;
+        c->samples_done = c->samples_added_end = sample_begin + spp;
         return PT_OK;
     }
 
@@ -1285,7 +1387,7 @@ int pt_write_accum(pt_ctx* c, const float* rgb, float spp) {
     PT_HIP(c, hipSetDevice(c->device));
     PT_HIP(c, hipMemcpy(c->d_accum.p, rgb, (size_t)c->cam.width * c->cam.height * 3 * sizeof(float), hipMemcpyHostToDevice));
     c->spp = c->spp_added = spp;
-    c->samples_done = (uint32_t)spp;
+    c->samples_done = c->samples_added_end = (uint32_t)spp;
     return PT_OK;
 }
 
@@ -1388,12 +1490,14 @@ int pt_get_counters(pt_ctx* c, pt_counters* out) {
     out->tail_launches = c->tail_launches;
     // timed launches may overlap (several batches or calls in flight): *_ms is the time during which at least one
     // such launch was running, *_ms_sum the plain sum of their durations (what a profiler's average x count gives)
-    out->tail_ms = union_ms(c->sched->tail_iv);
+    out->tail_ms = c->sched->tail_union_done + union_ms(c->sched->tail_iv);
     out->extend_launches = c->extend_launches;
-    out->extend_ms = union_ms(c->sched->ext_iv);
+    out->extend_ms = c->sched->ext_union_done + union_ms(c->sched->ext_iv);
     out->render_ms = c->render_ms;
     out->tail_ms_sum = c->sched->tail_sum;
     out->extend_ms_sum = c->sched->ext_sum;
+    out->redo_paths = c->redo_paths;
+    out->redo_restarts = c->redo_restarts;
     return PT_OK;
 }
 
@@ -1430,6 +1534,7 @@ int pt_set_option(pt_ctx* c, int option, uint64_t value) {
         case PT_OPT_DEVICE_BUILD: c->opt_device_build = value != 0; return PT_OK;
         case PT_OPT_MERGE_QUEUED_CALLS: c->opt_merge_calls = std::min<uint64_t>(value, kMaxSlots - 1); return PT_OK;
         case PT_OPT_TAIL_PATHS_PER_LANE: c->opt_tail_paths_per_lane = std::max<uint64_t>(value, 1); return PT_OK;
+        case PT_OPT_REDO_CAPACITY: c->opt_redo_cap = std::min<uint64_t>(value, 1u << 28); return PT_OK;
         default: return c->fail(PT_ERR_INVALID, "pt_set_option: unknown option");
     }
 }
@@ -1498,10 +1603,12 @@ int pt_reset_counters(pt_ctx* c) {
     c->extend_launches = 0;
     c->tail_launches = 0;
     c->render_ms = 0;
+    c->redo_paths = c->redo_restarts = 0;
     pt_sched& S = *c->sched;
     S.ext_iv.clear();
     S.tail_iv.clear();
     S.ext_sum = S.tail_sum = 0;
+    S.ext_union_done = S.tail_union_done = 0;
     if (S.ev_epoch) {
         (void)hipEventDestroy(S.ev_epoch);
         S.ev_epoch = nullptr;

@@ -476,7 +476,13 @@ __global__ __launch_bounds__(64) void k_small_wave(const uint32_t* __restrict__ 
             }
         }
         __syncthreads();
-        hazard = hazard || nl == 0 || nl == count;
+        // An empty child (bvh.rs:87-97 when float rounding makes the binning and the `<= pivot` test disagree): the full child
+        // would be split the same way again and again, past this subtree's block of nodes.  The wave stops before it writes
+        // or pushes the children; pt_build then fails with PT_ERR_BVH (nl comes from ballots: the same in every lane).
+        if (nl == 0 || nl == count) {
+            hazard = true;
+            break;
+        }
         const uint32_t L = 2 * nsplit;
         float box[2][6];
         for (int ch = 0; ch < 2; ++ch)
@@ -502,7 +508,7 @@ __global__ __launch_bounds__(64) void k_small_wave(const uint32_t* __restrict__ 
         }
         nsplit += 1;
         maxd = max(maxd, d + 1);
-        if (nsplit >= kSmall) break;  // cannot happen without the empty-child hazard (at most count - 1 splits)
+        if (nsplit >= kSmall) break;  // (cannot happen: at most count - 1 splits of non-empty sides)
         const uint32_t cnt[2] = {nl, count - nl};
         if (lane == 0) {
             int e = sp;
@@ -652,7 +658,15 @@ __global__ void k_children(const uint32_t* __restrict__ active, uint32_t n_activ
     }
     const uint32_t first = nodes[v].first, count = nodes[v].count;
     const uint32_t nl = P[first + count] - P[first];
-    if (nl == 0 || nl == count) atomicOr(&counters[2], 1u);
+    if (nl == 0 || nl == count) {
+        // the empty-child hazard: no children (the full one would be split the same way for ever, one level per pass and
+        // two nodes each, past the node array); the node is left as it is and the host ends the build after this level
+        atomicOr(&counters[2], 1u);
+        sp.axis = -1;
+        split[s] = sp;
+        nodes[v].slot = kNone;
+        return;
+    }
     const uint32_t pair = atomicAdd(&counters[0], 2u);
     BNode c;
     for (int a = 0; a < 3; ++a) { c.bmin[a] = c.cmin[a] = kKeyPosInf; c.bmax[a] = c.cmax[a] = kKeyNegInf; }
@@ -960,7 +974,8 @@ int build_bvh_device(int prim_kind, const float* d_geom, uint32_t n, DeviceTree&
         if (dbg) std::fprintf(stderr, "[ptcore] device build: %-22s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
         t_last = now;
     };
-    const uint32_t max_nodes = 2 * n + 1, max_active = n / 3 + 2, nb = (n + kScanTile - 1) / kScanTile;
+    // a node on the active list holds more than kSmall primitives, the root of a small subtree at least three
+    const uint32_t max_nodes = 2 * n + 1, max_active = n / (kSmall + 1) + 2, max_small = n / 3 + 2, nb = (n + kScanTile - 1) / kScanTile;
     Buf rec_a, rec_b, seg_a, seg_b, flags, P, lpos, sums, nodes, act_a, act_b, bins, split, counters, final_idx, splits, event, newid, outn;
     Buf small_rec, small_nodes, small_list, small_level, small_splits;
     Arena arena;  // declared after the Bufs: released first, while they still only point into it
@@ -980,8 +995,8 @@ int build_bvh_device(int prim_kind, const float* d_geom, uint32_t n, DeviceTree&
     arena.add(counters, 32);
     arena.add(small_rec, (size_t)n * sizeof(Rec));
     arena.add(small_nodes, (size_t)n * 2 * sizeof(pt_bvh_node));
-    arena.add(small_list, (size_t)max_active * 4);
-    arena.add(small_level, (size_t)max_active * 4);
+    arena.add(small_list, (size_t)max_small * 4);
+    arena.add(small_level, (size_t)max_small * 4);
     arena.add(small_splits, (size_t)max_nodes * 4);
     arena.add(splits, (size_t)max_nodes * 4);  // (the level nodes are at most max_nodes)
     arena.add(event, (size_t)max_nodes * 4);
@@ -1036,6 +1051,10 @@ int build_bvh_device(int prim_kind, const float* d_geom, uint32_t n, DeviceTree&
         BUILD_HIP(hipMemcpyAsync(h_cnt, counters.p, 12, hipMemcpyDeviceToHost, st));
         BUILD_HIP(hipStreamSynchronize(st));
         BUILD_HIP(hipGetLastError());
+        if (h_cnt[2]) {
+            if (err) *err = "pt_build: a partition produced an empty child";
+            return PT_ERR_BVH;
+        }
         if (h_cnt[0] > level_start.back()) level_start.push_back(h_cnt[0]);
         n_active = h_cnt[1];
         std::swap(rc, rn);

@@ -273,6 +273,9 @@ struct Builder {
             uint32_t ni = todo.back();
             todo.pop_back();
             if (nodes[ni].count > 2 && partition(ni)) {
+                // an empty child (bvh.rs:87-97 with float rounding against the binning): the reference would go on splitting
+                // the full child the same way for ever; the build stops here and reports PT_ERR_BVH
+                if (hazard) return;
                 uint32_t left = nodes[ni].left_first;
                 depth.resize(nodes.size());
                 depth[left] = depth[left + 1] = depth[ni] + 1;
@@ -299,7 +302,7 @@ void build_subtree(const pt_bvh_node& root, int threads, Builder& b) {
     b.nodes.clear();
     b.nodes.push_back(root);
     b.max_depth = 1;
-    if (!(root.count > 2 && b.partition(0))) return;
+    if (!(root.count > 2 && b.partition(0)) || b.hazard) return;
     const pt_bvh_node L = b.nodes[1], R = b.nodes[2];
     Builder bl(b.work, b.tmp, b.lpos), br(b.work, b.tmp, b.lpos);
     const uint64_t total = (uint64_t)L.count + R.count;

@@ -27,6 +27,18 @@ struct DevScene {
     uint32_t root_ref;
     uint32_t stack_cap;        // most entries a traversal can postpone (= tree levels - 1)
     float root_min[3], root_max[3];
+    // When the NEE block of camera.rs:314-338 may be left out (its weight min(1 - speculaty, 0) is exactly 0): only while
+    // every component of transport is at most nee_thr in magnitude (then the block's product is finite and 0 * it adds
+    // nothing), and never when nee_literal is set (a light whose area or colour is not finite).  See shade_core.
+    float nee_thr;
+    uint32_t nee_literal;
+};
+
+// Paths a kernel without the NEE code could not finish (transport beyond nee_thr at a diffuse hit): their slots, for k_redo.
+struct RedoList {
+    uint32_t* list;
+    uint32_t* count;   // entries asked for (may exceed cap: the host then runs the batch again with the NEE kernels)
+    uint32_t cap;
 };
 
 // Camera after update() (src/camera.rs:271-292), in device memory.
@@ -45,6 +57,7 @@ struct PathState {
     float4* out;  // radiance of the finished path
     float4* acc;  // accumalated_color while the path is alive (only scenes whose NEE weight is non-zero)
     uint2* pxs;   // pixel index (y * width + x) and global sample index: the RNG counter words
+    RedoList redo;
 };
 
 // CNT_NODE_TESTS / CNT_PRIM_TESTS are the round kernels' (k_extend, k_trace); the fused tail kernel keeps its own
@@ -106,8 +119,14 @@ void launch_tail(int prim, bool nee, bool count, int mode, const DevScene& S, co
                  uint32_t* cursor, uint32_t n_hint, uint32_t depth, uint32_t k0, uint32_t k1, const LaunchCfg& cfg, unsigned long long* counters,
                  hipStream_t st);
 void launch_path(int prim, bool nee, bool count, const DevScene& S, const DevCamera* cam, const PixelMap& M, uint32_t n_samples,
-                 uint32_t sample_base, uint32_t depth, uint32_t k0, uint32_t k1, float4* out, uint32_t* cursor, const LaunchCfg& cfg,
-                 unsigned long long* counters, hipStream_t st);
+                 uint32_t sample_base, uint32_t depth, uint32_t k0, uint32_t k1, float4* out, uint32_t* cursor, const RedoList& redo,
+                 const LaunchCfg& cfg, unsigned long long* counters, hipStream_t st);
+// the paths on a redo list, start to end, with the NEE code (one lane per path); pixel_major = the slot layout of k_path
+void launch_redo(int prim, bool count, const DevScene& S, const DevCamera* cam, const PixelMap& M, uint32_t n_samples, bool pixel_major,
+                 uint32_t sample_base, uint32_t depth, uint32_t k0, uint32_t k1, float4* out, const uint32_t* list, uint32_t n,
+                 const LaunchCfg& cfg, unsigned long long* counters, hipStream_t st);
+// flag[0] |= 1 if a light's Primitive::area() is not a finite number >= 0 (such a scene always runs the NEE block)
+void launch_light_check(int prim, const DevScene& S, uint32_t* flag, hipStream_t st);
 void launch_accumulate(const PixelMap& M, const float4* out, uint32_t n_samples, bool pixel_major, float* accum, hipStream_t st);
 void launch_shard_copy(const PixelMap& M, float* accum, float* slab, bool unpack, hipStream_t st);
 void launch_resolve(const float* accum, uint32_t width, uint32_t height, float scale, uint8_t* rgb, uint64_t pitch, hipStream_t st);

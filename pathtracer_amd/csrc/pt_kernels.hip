@@ -116,9 +116,9 @@ __device__ __forceinline__ void traverse(const DevScene& S, V3 o, V3 d, float& d
                 count = S.big_leaf[2 * first + 1];
                 first = S.big_leaf[2 * first];
             }
-            if (COUNT) n_prim_tests += count;
             for (uint32_t k = 0; k < count; ++k) {
                 const uint32_t slot = first + k;
+                if (COUNT) n_prim_tests += 1;  // per call: intersect_any leaves the leaf at its first hit (bvh.rs:246-248)
                 if (PRIM == PRIM_TRIANGLE) {
                     const float4* tp = S.prim + (size_t)slot * kTriStride;
                     const float4 a = tp[0], b = tp[1], c = tp[2];
@@ -865,11 +865,29 @@ struct HitVals {
 };
 
 // One step of the loop body of Camera::sample (src/camera.rs:299-421) for one path.
-// Returns true when the path stays alive (pv then holds its next ray); false when it ended
-// (radiance then holds what Camera::sample returns).
+// Returns SHADE_ALIVE when the path stays alive (pv then holds its next ray), SHADE_END when it ended (radiance then
+// holds what Camera::sample returns), and — kernels without the NEE code only — SHADE_REDO when the path met a diffuse
+// hit at which the NEE block of camera.rs:314-338 may not be left out: the caller puts its slot on the redo list and
+// k_redo runs the whole path again with the NEE code.
+//
+// When the block may be left out.  Its contribution is min(1 - speculaty, 0) * n_lights * transport (*) (cos / mis) * light
+// colour (*) brdf (camera.rs:333).  With the weight exactly 0 that is 0 * X, and acc + (+-0) == acc bit for bit — provided X
+// is finite; 0 * inf and 0 * NaN are NaN, and the reference then returns a NaN pixel.  cos / mis <= pi (both pdfs are >= 0
+// once cos_i > 0 and cos_l > 0 hold and the light's area is a finite number >= 0), colour (*) brdf is bounded by a per-scene
+// constant, so X is finite whenever |transport| <= nee_thr (pt_api.cpp: FLT_MAX / (3.25 * largest |light colour * brdf|)).
+// A transport beyond that (inf and NaN included: the unguarded light pdf of camera.rs:361-370 makes some) runs the block,
+// and so does every diffuse hit of a scene whose lights have a non-finite area or colour (nee_literal).
+// What is left out of this argument: cos / mis is also non-finite when mis == 0, i.e. the light pdf is 0 (the sampled point
+// exactly f32::EPSILON from the surface) AND cos_i / pi underflows to 0; no input is known to reach it.
+enum { SHADE_END = 0, SHADE_ALIVE = 1, SHADE_REDO = 2 };
+// the work of the NEE blocks a shade_core call ran, for the counters of instrumented launches
+struct NeeWork {
+    uint32_t blocks;            // one Primitive::intersect on the light itself per block (camera.rs:321)
+    uint32_t node_tests, prim_tests;  // of its intersect_any traversal
+};
 template <int PRIM, bool NEE>
-__device__ __forceinline__ bool shade_core(const DevScene& S, PathVals& pv, const HitVals& hv, uint32_t depth, uint32_t k0, uint32_t k1,
-                                           LaneStack stk, unsigned long long* counters, V3& radiance) {
+__device__ __forceinline__ int shade_core(const DevScene& S, PathVals& pv, const HitVals& hv, uint32_t depth, uint32_t k0, uint32_t k1,
+                                          LaneStack stk, unsigned long long* counters, V3& radiance, NeeWork& nee_work) {
     const V3 o = pv.o, d = pv.d;
     V3 transport = pv.transport;
     const uint32_t flags = pv.flags;
@@ -902,17 +920,17 @@ __device__ __forceinline__ bool shade_core(const DevScene& S, PathVals& pv, cons
         const float mis = light_pdf + hemi_pdf;
         transport = mul_ew(transport, (cos_i / mis) * brdf);
         it += 1;
-        if (it >= depth) { radiance = acc; return false; }
+        if (it >= depth) { radiance = acc; return SHADE_END; }
         // the next iteration re-traces this ray with the shortened ray.distance (quirk Q3)
         pv.tmax = t;
         pv.transport = transport;
         pv.flags = it;
-        return true;
+        return SHADE_ALIVE;
     }
 
     if (!is_hit) {  // camera.rs:301-304
         radiance = acc + mul_ew(transport, 0.1f * sky_lookup(S, d));
-        return false;
+        return SHADE_END;
     }
     const V3 Pt = o + t * d;  // ray.intersection(), ray.rs:33-35
     const Surface sf = surface_at<PRIM>(S, hslot, hv.u, hv.v, o, d, t, false);
@@ -923,15 +941,20 @@ __device__ __forceinline__ bool shade_core(const DevScene& S, PathVals& pv, cons
 
     if (m.kind == PT_MAT_EMISSIVE) {  // camera.rs:308-311
         radiance = acc + mul_ew(transport, color);
-        return false;
+        return SHADE_END;
     } else if (m.kind == PT_MAT_DIFFUSE) {  // camera.rs:312-374
         const float speculaty = m.a;
-        if (inside) { radiance = acc; return false; }
+        if (inside) { radiance = acc; return SHADE_END; }
+        // a transport the block's product may not be finite with (NaN fails the comparisons too)
+        const bool beyond = S.n_lights != 0 && !(__builtin_fabsf(transport.x) <= S.nee_thr && __builtin_fabsf(transport.y) <= S.nee_thr &&
+                                                 __builtin_fabsf(transport.z) <= S.nee_thr);
+        if (!NEE && beyond) return SHADE_REDO;
         if (NEE) {
-            // camera.rs:314-338.  Its weight min(1 - speculaty, 0) is exactly 0 unless speculaty > 1,
-            // and then the block adds nothing, so it only runs when the weight is non-zero.
+            // camera.rs:314-338.  Its weight min(1 - speculaty, 0) is exactly 0 unless speculaty > 1; the block is left out
+            // only where that provably adds nothing (see above).
             const float nee_w = fmin_(1.0f - speculaty, 0.0f);
-            if (S.n_lights != 0 && nee_w != 0.0f) {
+            if (S.n_lights != 0 && (nee_w != 0.0f || S.nee_literal != 0u || beyond)) {
+                nee_work.blocks += 1;
                 const U4 rn = philox4x32_10(k0, k1, px.x, px.y, 1u + it, 1u);
                 // BVH::random_light, bvh.rs:273-284: Range<usize>::ind_sample rejects draws at or above the largest
                 // multiple of the range and returns draw % range (rand 0.3.15); rejected draws are replaced by
@@ -992,9 +1015,8 @@ __device__ __forceinline__ bool shade_core(const DevScene& S, PathVals& pv, cons
                         gdist -= kEps;
                         const float gd = gdist;
                         Hit sh;
-                        uint32_t nn = 0, np = 0;
                         float dist2 = gdist;
-                        traverse<PRIM, true, false>(S, go, ldir, dist2, sh, stk, nn, np);
+                        traverse<PRIM, true, true>(S, go, ldir, dist2, sh, stk, nee_work.node_tests, nee_work.prim_tests);
                         atomicAdd(counters + CNT_RAYS_ANY, 1ull);
                         if (sh.slot == PT_MISS) {
                             const V3 brdf = kFrac1Pi * color;
@@ -1021,7 +1043,7 @@ __device__ __forceinline__ bool shade_core(const DevScene& S, PathVals& pv, cons
             tm = tm > transport.z ? tm : transport.z;
             const float survival = fmax_(tm, 0.1f);
             if (rr < survival) transport = transport / survival;
-            else { radiance = acc; return false; }
+            else { radiance = acc; return SHADE_END; }
             nd = cosine_weighted_diffuse(normal, closed01(r.v[2]), closed01(r.v[3]));
             const V3 no = advance(Pt, nd);
             const float cos_i = dot(nd, normal);
@@ -1032,7 +1054,7 @@ __device__ __forceinline__ bool shade_core(const DevScene& S, PathVals& pv, cons
             pv.transport = transport;
             pv.flags = it | kPhaseBit | (sf.mat << kMatShift);
             if (NEE) pv.acc = acc;
-            return true;
+            return SHADE_ALIVE;
         }
     } else {  // Dielectric, camera.rs:375-417
         const float n1 = m.a, n2 = m.b;
@@ -1058,7 +1080,7 @@ __device__ __forceinline__ bool shade_core(const DevScene& S, PathVals& pv, cons
     }
     // ray.reset(P, nd, inf) and on to the next iteration
     it += 1;
-    if (it >= depth) { radiance = acc; return false; }
+    if (it >= depth) { radiance = acc; return SHADE_END; }
     pv.o = advance(Pt, nd);
     pv.d = nd;
     pv.tmax = kInf;
@@ -1066,7 +1088,12 @@ __device__ __forceinline__ bool shade_core(const DevScene& S, PathVals& pv, cons
     pv.transport = transport;
     pv.flags = it;
     if (NEE) pv.acc = acc;
-    return true;
+    return SHADE_ALIVE;
+}
+
+__device__ __forceinline__ void redo_push(const RedoList& R, uint32_t slot) {
+    const uint32_t at = atomicAdd(R.count, 1u);
+    if (at < R.cap) R.list[at] = slot;
 }
 
 // shade_core on a path whose state lives in HBM (the wavefront round kernel and the queue-fed tail kernel)
@@ -1092,7 +1119,13 @@ __device__ __forceinline__ bool shade_one(const DevScene& S, const PathState& P,
     hv.u = h.z;
     hv.v = h.w;
     V3 radiance;
-    if (!shade_core<PRIM, NEE>(S, pv, hv, depth, k0, k1, stk, counters, radiance)) {
+    NeeWork nee_work{0, 0, 0};
+    const int status = shade_core<PRIM, NEE>(S, pv, hv, depth, k0, k1, stk, counters, radiance, nee_work);
+    if (status == SHADE_REDO) {  // k_redo finishes this path (and writes its P.out) before the batch is accumulated
+        redo_push(P.redo, slot);
+        return false;
+    }
+    if (status == SHADE_END) {
         P.out[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
         return false;
     }
@@ -1288,7 +1321,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_tail_pw(DevScene S, PathState P
 template <int PRIM, bool NEE, bool COUNT>
 __global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, const DevCamera* __restrict__ camp, PixelMap M, uint32_t n_samples, FastDiv fd_samples,
                                                       uint32_t sample_base, uint32_t depth, uint32_t k0, uint32_t k1,
-                                                      float4* __restrict__ out, uint32_t* __restrict__ cursor, LaunchCfg cfg,
+                                                      float4* __restrict__ out, uint32_t* __restrict__ cursor, RedoList redo, LaunchCfg cfg,
                                                       unsigned long long* counters) {
     __shared__ unsigned long long smem[kLdsStack * kTraceBlock];
     LaneStack stk = make_stack(smem, cfg);
@@ -1341,12 +1374,17 @@ __global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, c
                     pv.sample = sample_base + (T.slot - pix_idx * n_samples);
                 }
                 V3 radiance;
-                if (shade_core<PRIM, NEE>(S, pv, hv, depth, k0, k1, stk, counters, radiance)) {
+                NeeWork nee_work{0, 0, 0};
+                const int status = shade_core<PRIM, NEE>(S, pv, hv, depth, k0, k1, stk, counters, radiance, nee_work);
+                if (COUNT && NEE) { nn += nee_work.node_tests; np += nee_work.blocks + nee_work.prim_tests; }
+                if (status == SHADE_ALIVE) {
                     traced = true;
                     active = lane_start_ray<COUNT>(S, T, make_float4(pv.o.x, pv.o.y, pv.o.z, pv.tmax), make_float4(pv.d.x, pv.d.y, pv.d.z, 0.f), nn, mine);
                     pending = !active;  // a ray that misses the root box is shaded as a miss
-                } else {
+                } else if (status == SHADE_END) {
                     out[T.slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+                } else {
+                    redo_push(redo, T.slot);  // k_redo runs this path again, with the NEE code, before the batch is accumulated
                 }
             }
             rays += (uint32_t)__popcll(__ballot(traced));
@@ -1458,6 +1496,82 @@ __global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, c
         wave_add(counters + CNT_TAIL_NODE_TESTS, nn);
         wave_add(counters + CNT_TAIL_PRIM_TESTS, np);
         reduce_worst(counters, worst);
+    }
+}
+
+// k_redo — the paths a kernel without the NEE code gave up (SHADE_REDO), run again from generate() with the NEE code,
+// one lane per path.  A path is a function of (pixel, sample, seed), so the second run reaches the giving-up point in the
+// same state, takes the NEE block there and goes on.  The first run has already counted the path and every ray up to
+// that point; this kernel counts only what comes after (the block runs for the first time exactly there: before it the
+// transport was within nee_thr, and these scenes have no non-zero NEE weight).  A handful of paths per frame at most
+// (C3: the unguarded light pdf of camera.rs:361-370 makes ~0.3 non-finite samples per million), so nothing here is tuned.
+template <int PRIM, bool COUNT>
+__global__ __launch_bounds__(kTraceBlock) void k_redo(DevScene S, const DevCamera* __restrict__ camp, PixelMap M, uint32_t n_samples, int pixel_major,
+                                                      uint32_t sample_base, uint32_t depth, uint32_t k0, uint32_t k1, float4* __restrict__ out,
+                                                      const uint32_t* __restrict__ list, uint32_t n, LaunchCfg cfg, unsigned long long* counters) {
+    __shared__ unsigned long long smem[kLdsStack * kTraceBlock];
+    LaneStack stk = make_stack(smem, cfg);
+    const DevCamera cam = *camp;
+    uint32_t rays = 0, nn = 0, np = 0;
+    for (uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x; i < n; i += gridDim.x * kTraceBlock) {
+        const uint32_t slot = list[i];
+        // slab layout: [pixel][sample] from k_path, [sample][pixel] from the wavefront kernels
+        const uint32_t pix_idx = pixel_major ? slot / n_samples : slot % M.npix_pad;
+        const uint32_t s_local = pixel_major ? slot % n_samples : slot / M.npix_pad;
+        uint32_t x, y;
+        map_pixel(M, pix_idx, &x, &y);
+        PathVals pv;
+        pv.pixel = y * M.width + x;
+        pv.sample = sample_base + s_local;
+        generate_ray(cam, x, y, pv.sample, k0, k1, &pv.o, &pv.d);
+        pv.tmax = kInf;
+        pv.cos_i = 0.f;
+        pv.transport = V3{1.f, 1.f, 1.f};
+        pv.flags = 0;
+        pv.acc = V3{0.f, 0.f, 0.f};
+        V3 radiance = V3{0.f, 0.f, 0.f};
+        bool counting = false;
+        while (true) {
+            float dist = pv.tmax;
+            Hit h;
+            uint32_t a = 0, b = 0;
+            traverse<PRIM, false, COUNT>(S, pv.o, pv.d, dist, h, stk, a, b);
+            if (counting) { rays += 1; nn += a; np += b; }
+            HitVals hv;
+            hv.bits = h.slot == PT_MISS ? PT_MISS : (h.slot | (h.inside << 31));
+            hv.t = dist;
+            hv.u = h.u;
+            hv.v = h.v;
+            NeeWork nee_work{0, 0, 0};
+            const int status = shade_core<PRIM, true>(S, pv, hv, depth, k0, k1, stk, counters, radiance, nee_work);
+            if (nee_work.blocks) { counting = true; nn += nee_work.node_tests; np += nee_work.blocks + nee_work.prim_tests; }
+            if (status != SHADE_ALIVE) break;
+        }
+        out[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+    }
+    wave_add(counters + CNT_RAYS_CLOSEST, rays);
+    wave_add(counters + CNT_TAIL_RAYS, rays);
+    if (COUNT) {
+        wave_add(counters + CNT_TAIL_NODE_TESTS, nn);
+        wave_add(counters + CNT_TAIL_PRIM_TESTS, np);
+    }
+}
+
+// Primitive::area() of every light (triangle.rs:105-113, sphere.rs:119-121) must be a finite number >= 0 for the bound
+// on cos / mis that lets the NEE block be left out (shade_core); otherwise flag[0] is set and the block always runs.
+template <int PRIM>
+__global__ void k_light_check(DevScene S, uint32_t* __restrict__ flag) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < S.n_lights; i += gridDim.x * blockDim.x) {
+        const uint32_t slot = S.lights[i];
+        float area;
+        if (PRIM == PRIM_TRIANGLE) {
+            const float4* tp = S.prim + (size_t)slot * kTriStride;
+            const float4 a = tp[0], b = tp[1], c = tp[2];
+            area = tri_area(V3{a.w, b.x, b.y}, V3{b.z, b.w, c.x});
+        } else {
+            area = sphere_area(S.prim[slot].w);
+        }
+        if (!(area >= 0.0f && area <= 3.402823466e38f)) atomicOr(flag, 1u);
     }
 }
 
@@ -1615,11 +1729,11 @@ void launch_tail(int prim, bool nee, bool count, int mode, const DevScene& S, co
 }
 
 void launch_path(int prim, bool nee, bool count, const DevScene& S, const DevCamera* cam, const PixelMap& M, uint32_t n_samples,
-                 uint32_t sample_base, uint32_t depth, uint32_t k0, uint32_t k1, float4* out, uint32_t* cursor, const LaunchCfg& cfg,
-                 unsigned long long* counters, hipStream_t st) {
+                 uint32_t sample_base, uint32_t depth, uint32_t k0, uint32_t k1, float4* out, uint32_t* cursor, const RedoList& redo,
+                 const LaunchCfg& cfg, unsigned long long* counters, hipStream_t st) {
     const uint64_t total = (uint64_t)n_samples * M.npix_pad;
     const uint32_t grid = blocks_for(total, kTraceBlock, cfg.grid);
-#define PT_PATH(PR, N, C) hipLaunchKernelGGL((k_path<PR, N, C>), dim3(grid), dim3(kTraceBlock), 0, st, S, cam, M, n_samples, fastdiv_make(n_samples), sample_base, depth, k0, k1, out, cursor, cfg, counters)
+#define PT_PATH(PR, N, C) hipLaunchKernelGGL((k_path<PR, N, C>), dim3(grid), dim3(kTraceBlock), 0, st, S, cam, M, n_samples, fastdiv_make(n_samples), sample_base, depth, k0, k1, out, cursor, redo, cfg, counters)
     if (prim == PRIM_TRIANGLE) {
         if (nee) { if (count) PT_PATH(PRIM_TRIANGLE, true, true); else PT_PATH(PRIM_TRIANGLE, true, false); }
         else { if (count) PT_PATH(PRIM_TRIANGLE, false, true); else PT_PATH(PRIM_TRIANGLE, false, false); }
@@ -1628,6 +1742,22 @@ void launch_path(int prim, bool nee, bool count, const DevScene& S, const DevCam
         else { if (count) PT_PATH(PRIM_SPHERE, false, true); else PT_PATH(PRIM_SPHERE, false, false); }
     }
 #undef PT_PATH
+}
+
+void launch_redo(int prim, bool count, const DevScene& S, const DevCamera* cam, const PixelMap& M, uint32_t n_samples, bool pixel_major,
+                 uint32_t sample_base, uint32_t depth, uint32_t k0, uint32_t k1, float4* out, const uint32_t* list, uint32_t n,
+                 const LaunchCfg& cfg, unsigned long long* counters, hipStream_t st) {
+    const uint32_t grid = blocks_for(n, kTraceBlock, cfg.grid < 1024u ? cfg.grid : 1024u);  // a lane's spill column is its global thread id: stay inside cfg.grid
+#define PT_REDO(PR, C) hipLaunchKernelGGL((k_redo<PR, C>), dim3(grid), dim3(kTraceBlock), 0, st, S, cam, M, n_samples, pixel_major ? 1 : 0, sample_base, depth, k0, k1, out, list, n, cfg, counters)
+    if (prim == PRIM_TRIANGLE) { if (count) PT_REDO(PRIM_TRIANGLE, true); else PT_REDO(PRIM_TRIANGLE, false); }
+    else { if (count) PT_REDO(PRIM_SPHERE, true); else PT_REDO(PRIM_SPHERE, false); }
+#undef PT_REDO
+}
+
+void launch_light_check(int prim, const DevScene& S, uint32_t* flag, hipStream_t st) {
+    const uint32_t grid = blocks_for(S.n_lights, 256, 1024);
+    if (prim == PRIM_TRIANGLE) hipLaunchKernelGGL((k_light_check<PRIM_TRIANGLE>), dim3(grid), dim3(256), 0, st, S, flag);
+    else hipLaunchKernelGGL((k_light_check<PRIM_SPHERE>), dim3(grid), dim3(256), 0, st, S, flag);
 }
 
 void launch_accumulate(const PixelMap& M, const float4* out, uint32_t n_samples, bool pixel_major, float* accum, hipStream_t st) {

@@ -94,6 +94,9 @@ struct DeviceBuffer {
     void alloc_zero(size_t n_floats) {
         hip_check(hipMalloc((void**)&p, n_floats * sizeof(float)), "hipMalloc(slab)");
         hip_check(hipMemset(p, 0, n_floats * sizeof(float)), "hipMemset(slab)");
+        // the fill runs on the null stream and need not have finished when hipMemset returns; the library's streams do not
+        // wait for the null stream (hipStreamNonBlocking), so a pack kernel could otherwise be overwritten by it
+        hip_check(hipStreamSynchronize(nullptr), "hipStreamSynchronize(null)");
     }
 };
 

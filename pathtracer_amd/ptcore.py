@@ -33,7 +33,7 @@ PT_OK = 0
 PT_ERR_INVALID, PT_ERR_STATE, PT_ERR_NO_DEVICE, PT_ERR_HIP, PT_ERR_LIMIT, PT_ERR_BVH = -1, -2, -3, -4, -5, -6
 SHARD_ALL, SHARD_TILES = 0, 1
 RENDER_TIMED, RENDER_COUNT = 1, 2
-OPT_BATCH_PATHS, OPT_LANES, OPT_TAIL_MIN_PATHS, OPT_TAIL_FRACTION, OPT_TAIL_STREAMS, OPT_TAIL_PATHS_PER_LANE, OPT_SIMPLE_EXTEND, OPT_BULK_STREAMS, OPT_TAIL_MODE, OPT_FIRST_CHECK_ROUND, OPT_RENDER_MODE, OPT_MERGE_QUEUED_CALLS, OPT_DEVICE_BUILD = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12
+OPT_BATCH_PATHS, OPT_LANES, OPT_TAIL_MIN_PATHS, OPT_TAIL_FRACTION, OPT_TAIL_STREAMS, OPT_TAIL_PATHS_PER_LANE, OPT_SIMPLE_EXTEND, OPT_BULK_STREAMS, OPT_TAIL_MODE, OPT_FIRST_CHECK_ROUND, OPT_RENDER_MODE, OPT_MERGE_QUEUED_CALLS, OPT_DEVICE_BUILD, OPT_REDO_CAPACITY = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13
 
 EXPORTS = [
     "pt_strerror", "pt_last_error", "pt_create", "pt_destroy", "pt_set_triangles", "pt_set_spheres", "pt_set_materials",
@@ -66,7 +66,8 @@ class Counters(C.Structure):
                 ("node_tests", C.c_uint64), ("prim_tests", C.c_uint64), ("extend_launches", C.c_uint64),
                 ("extend_ms", C.c_double), ("render_ms", C.c_double), ("tail_rays", C.c_uint64),
                 ("tail_node_tests", C.c_uint64), ("tail_prim_tests", C.c_uint64), ("tail_launches", C.c_uint64),
-                ("tail_ms", C.c_double), ("extend_ms_sum", C.c_double), ("tail_ms_sum", C.c_double)]
+                ("tail_ms", C.c_double), ("extend_ms_sum", C.c_double), ("tail_ms_sum", C.c_double),
+                ("redo_paths", C.c_uint64), ("redo_restarts", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

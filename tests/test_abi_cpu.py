@@ -31,7 +31,9 @@ def test_struct_layouts_match_header():
     assert scenes.MATERIAL_DTYPE.itemsize == 24
     assert C.sizeof(ptcore.CameraState) == 8 * 12 + 16
     assert C.sizeof(ptcore.Shard) == 20
-    assert C.sizeof(ptcore.Counters) == 120
+    assert C.sizeof(ptcore.Counters) == 136
+    from oracle import orc
+    assert C.sizeof(orc.Counters) == 136   # the oracle fills the header's pt_counters too
 
 
 def test_no_device_is_an_error_not_a_fallback():

@@ -33,7 +33,7 @@ def test_header_is_plain_c(tmp_path):
     src.write_text('#include "ptcore.h"\n#include "ptcore_detmath.h"\n'
                    "int main(void) { pt_shard s = {PT_SHARD_ALL, 0, 1, 0, 0}; pt_counters c; (void)c;\n"
                    "  return (int)s.kind + (sizeof(pt_ray) == 28 && sizeof(pt_hit) == 12 && sizeof(pt_bvh_node) == 32 && sizeof(pt_material) == 24\n"
-                   "                        && sizeof(pt_camera_state) == 112 && sizeof(pt_shard) == 20 && sizeof(pt_counters) == 120 ? 0 : 1); }\n")
+                   "                        && sizeof(pt_camera_state) == 112 && sizeof(pt_shard) == 20 && sizeof(pt_counters) == 136 ? 0 : 1); }\n")
     exe = tmp_path / "use_header"
     r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-pedantic", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"),
                         str(src), "-o", str(exe)], capture_output=True, text=True)
@@ -72,7 +72,7 @@ def test_rust_struct_sizes_match():
     """Field-by-field size of the #[repr(C)] mirrors (all fields are 4 or 8 bytes wide and naturally aligned)."""
     text = open(RUST).read()
     width = {"u32": 4, "f32": 4, "u64": 8, "f64": 8}
-    want = {"pt_material": 24, "pt_ray": 28, "pt_hit": 12, "pt_bvh_node": 32, "pt_camera_state": 112, "pt_shard": 20, "pt_counters": 120}
+    want = {"pt_material": 24, "pt_ray": 28, "pt_hit": 12, "pt_bvh_node": 32, "pt_camera_state": 112, "pt_shard": 20, "pt_counters": 136}
     for name, size in want.items():
         body = re.search(r"pub struct %s \{(.*?)\n\}" % name, text, flags=re.S).group(1)
         total = 0

@@ -142,6 +142,45 @@ def test_device_build_equals_host_build(ptcore, sky):
         g.close()
 
 
+@pytest.mark.parametrize("name", ["wave", "level", "deep", "threads", "large"])
+def test_device_build_reports_the_empty_child_hazard(ptcore, orc, sky, name):
+    """The builders on the GPU meet bvh.rs:87-97's empty child (tests/hazard_scenes.py) where the host builder and the oracle
+    do — in the one-wave subtrees (k_small_wave stops before it writes the children: going on would run past the subtree's
+    block of nodes) and in the level passes (k_children creates no children; the host ends the build after that level
+    instead of adding two nodes per level for ever) — and pt_build returns PT_ERR_BVH.  The context stays usable."""
+    from hazard_scenes import HAZARD_SCENES
+    cr = HAZARD_SCENES[name]()
+    mats = scenes.materials([scenes.diffuse(0.0, (1, 1, 1))])
+    g = ptcore.PathTracer(0)
+    try:
+        for device_build in (1, 0):
+            g.set_option(ptcore.OPT_DEVICE_BUILD, device_build)
+            g.set_materials(mats)
+            g.set_spheres(cr, np.zeros(len(cr), np.uint32))
+            with pytest.raises(ptcore.PtError) as e:
+                g.build()
+            assert e.value.status == ptcore.PT_ERR_BVH, device_build
+            with pytest.raises(ptcore.PtError) as e:
+                g.trace(scenes.random_rays(16))
+            assert e.value.status == ptcore.PT_ERR_STATE
+        # the same context, the same spheres away from 2^24: builds on the GPU and traces like the oracle
+        g.set_option(ptcore.OPT_DEVICE_BUILD, 1)
+        ok = cr.copy()
+        ok[:, 0] -= np.float32(2.0 ** 24)
+        scene = (ok, np.zeros(len(ok), np.uint32), mats)
+        g.set_scene(scene, sky)
+        assert g.build_info()[0]
+        o = orc.from_scene(scene, sky)
+        gn, gi, gd = g.bvh()
+        on, oi, od = o.bvh()
+        assert gn.tobytes() == on.tobytes() and np.array_equal(gi, oi) and gd == od
+        rays = scenes.random_rays(4096, seed=4, box=((-20, -20, -20), (20, 20, 20)), aim=(5.0, 0.0, 0.0), aim_sigma=6.0)
+        assert_hits_equal(g.trace(rays), o.trace(rays))
+        o.close()
+    finally:
+        g.close()
+
+
 def test_device_built_scene_renders_like_host_built_scene(ptcore, sky):
     """Flattening and the leaf-order gather also run on the device after a device build (k_flatten, k_reorder_*), and
     number the large-leaf table in node order instead of parent order: hits, frames and the tree read back lazily
@@ -377,6 +416,68 @@ def test_negative_nee_weight_scene(ptcore, orc, sky):
     assert ga.tobytes() == oa.tobytes()
     assert g.counters()["rays_any"] == o.counters()["rays_any"] > 0
     g.close()
+
+
+@pytest.mark.parametrize("name", ["absorbing_glass", "overflowing_mirrors", "infinite_light", "degenerate_light", "absorbing_glass_spheres"])
+def test_nee_block_runs_where_it_can_change_a_sum(ptcore, orc, sky, name):
+    """Quirk Q2 closed against the loop AS WRITTEN (camera.rs:314-338, oracle nee_mode 0): the device leaves the NEE block out
+    where its weight is 0, but 0 * (a product that is not finite) is NaN in the reference, so a path whose transport is beyond
+    the scene's threshold (inf and NaN included) is finished by the second, literal pass (k_redo), and a scene whose lights make
+    the product non-finite by themselves runs the NEE kernels throughout.  Scenes built to make it show (tests/nee_scenes.py;
+    tests/test_nee_rule_cpu.py shows that round 2's rule fails them): same sums as the literal oracle in both schedulings,
+    with the redo list at its default size, too small (3) and absent (0: the batch is run again with the NEE kernels), and
+    the same ray / node / primitive counts as the oracle's restatement of the device rule (nee_mode 1)."""
+    from nee_scenes import NEE_SCENES
+    make, cam_o, cam_t, expects_redo = NEE_SCENES[name]
+    scene = make()
+    g = ptcore.PathTracer(0).set_scene(scene, sky)
+    o = orc.from_scene(scene, sky)
+    W, H, spp = 96, 64, 3
+    try:
+        o.set_camera(cam_o, cam_t, W, H)
+        o.render(spp, 32, seed=23, nthreads=8, nee_mode=0)
+        want = o.read_accum()[0].copy()
+        o.set_camera(cam_o, cam_t, W, H)
+        o.reset_counters()
+        o.render(spp, 32, seed=23, nthreads=8, nee_mode=1)
+        assert o.read_accum()[0].tobytes() == want.tobytes()
+        oc = o.counters()
+        if name != "degenerate_light":
+            assert (~np.isfinite(want)).sum() > 50
+        for mode in (1, 0):
+            g.set_option(ptcore.OPT_RENDER_MODE, mode)
+            for cap in (65536, 3, 0):
+                g.set_option(ptcore.OPT_REDO_CAPACITY, cap)
+                g.set_camera(cam_o, cam_t, W, H)
+                g.reset_counters()
+                g.render(spp, 32, seed=23, flags=ptcore.RENDER_COUNT)
+                got = g.read_accum()[0]
+                assert got.tobytes() == want.tobytes(), (mode, cap)
+                c = g.counters()
+                if expects_redo:
+                    if cap == 65536:
+                        assert c["redo_paths"] > 10 and c["redo_restarts"] == 0, (mode, cap, c)
+                        for k in ("paths", "rays_closest", "rays_any", "node_tests", "prim_tests"):
+                            assert int(c[k]) == int(oc[k]), (mode, k)
+                    else:
+                        assert c["redo_restarts"] == 1 and c["redo_paths"] == 0, (mode, cap, c)
+                else:
+                    assert c["redo_paths"] == 0 and c["redo_restarts"] == 0
+                    assert c["rays_any"] == oc["rays_any"] > 0 and c["rays_closest"] == oc["rays_closest"]
+                    if mode == 1:   # (the wavefront rounds' shade kernel has no instrumented variant)
+                        for k in ("paths", "node_tests", "prim_tests"):
+                            assert int(c[k]) == int(oc[k]), (mode, k)
+        # queued one-sample calls take the same route
+        g.set_option(ptcore.OPT_RENDER_MODE, 1)
+        g.set_option(ptcore.OPT_REDO_CAPACITY, 65536)
+        g.set_camera(cam_o, cam_t, W, H)
+        for _ in range(spp):
+            g.render_async(1, 32, seed=23)
+        assert g.read_accum()[0].tobytes() == want.tobytes()
+    finally:
+        g.set_option(ptcore.OPT_RENDER_MODE, 1)
+        g.close()
+        o.close()
 
 
 def test_sphere_lights_sampled_bit_exact(ptcore, orc, sky):
@@ -733,6 +834,29 @@ def test_full_size_workloads(ptcore, orc, sky, big_scenes, name):
         got = full[xy[:, 1], xy[:, 0]]
         assert got.tobytes() == want.astype(np.float32).tobytes()
         assert np.abs(got).sum() > 0
+        # ... and against the loop AS WRITTEN (camera.rs:314-338, nee_mode 0: the NEE block at every diffuse hit, its 0 weight
+        # multiplied into the transport).  It can only differ from the device's rule where a sum is not finite, so the
+        # sample set is made to contain such samples: single samples are rendered until some pixels come out non-finite
+        # (the unguarded light pdf of camera.rs:361-370 makes a few per million), and those (pixel, sample) pairs plus 300
+        # ordinary pixels per sample are compared with the literal oracle.
+        odd, tried = 0, 0
+        for s_idx in range(2, 66):
+            g.reset_accum()
+            g.render(1, depth, seed=seed, shard=ptcore.Shard(ptcore.SHARD_ALL, 0, 1, 0, s_idx))
+            one = g.read_accum()[0]
+            tried += 1
+            ys, xs = np.nonzero(~np.isfinite(one).all(axis=2))
+            if len(ys) == 0:
+                continue
+            pick = np.concatenate([np.stack([xs, ys], axis=1)[:64].astype(np.uint32), xy[:300]])
+            lit = o.sample_pixels(pick, s_idx, depth, seed, nee_mode=0).astype(np.float32)
+            assert one[pick[:, 1], pick[:, 0]].tobytes() == lit.tobytes(), s_idx
+            odd += min(len(ys), 64)
+            if odd >= 8 or (odd and tried >= 24):
+                break
+        assert odd > 0, f"no non-finite sample in {tried} samples of {name}"
+        print(f"{name}: {odd} non-finite samples among {tried} single-sample frames equal the literal loop; redo paths so far {g.counters()['redo_paths']}")
+        g.reset_accum()
 
         g.set_option(ptcore.OPT_RENDER_MODE, 0)  # wavefront rounds + tail kernel
         g.reset_accum()
