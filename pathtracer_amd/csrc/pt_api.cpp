@@ -649,6 +649,7 @@ static int finalize_scene(pt_ctx* c) {
     S.lights = (const uint32_t*)c->d_lights.p;
     S.n_lights = (uint32_t)light_slots.size();
     S.n_prims = (uint32_t)n;
+    S.n_pairs = (uint32_t)(c->d_pairs.bytes / sizeof(PairRecord));
     S.root_ref = root_ref;
     S.stack_cap = c->bvh.max_depth > 0 ? c->bvh.max_depth - 1 : 0;
     for (int a = 0; a < 3; ++a) {
@@ -1535,6 +1536,7 @@ int pt_set_option(pt_ctx* c, int option, uint64_t value) {
         case PT_OPT_MERGE_QUEUED_CALLS: c->opt_merge_calls = std::min<uint64_t>(value, kMaxSlots - 1); return PT_OK;
         case PT_OPT_TAIL_PATHS_PER_LANE: c->opt_tail_paths_per_lane = std::max<uint64_t>(value, 1); return PT_OK;
         case PT_OPT_REDO_CAPACITY: c->opt_redo_cap = std::min<uint64_t>(value, 1u << 28); return PT_OK;
+        case PT_OPT_SKIP_REPEATED_MISS: c->ds.skip_repeated_miss = value ? 1u : 0u; return PT_OK;
         default: return c->fail(PT_ERR_INVALID, "pt_set_option: unknown option");
     }
 }

@@ -864,7 +864,7 @@ __global__ void k_node_flags(const pt_bvh_node* __restrict__ nodes, uint32_t n_n
 
 __device__ __forceinline__ uint32_t make_ref(const pt_bvh_node& nd, uint32_t id, const uint32_t* pair_of, const uint32_t* big_of, uint32_t big_from,
                                              uint32_t* big_leaf) {
-    if (nd.count == 0) return pair_of[id];
+    if (nd.count == 0) return kPairDfs ? nd.left_first >> 1 : pair_of[id];
     if (nd.count < big_from && nd.count <= 31) return kLeafBit | (nd.count << kLeafCountShift) | nd.left_first;
     const uint32_t slot = big_of[id];
     big_leaf[2 * slot] = nd.left_first;
@@ -888,7 +888,7 @@ __global__ void k_flatten(const pt_bvh_node* __restrict__ nodes, uint32_t n_node
     p.lref = make_ref(l, nd.left_first, pair_of, big_of, big_from, big_leaf);
     p.rref = make_ref(r, nd.left_first + 1, pair_of, big_of, big_from, big_leaf);
     p.lpad = p.rpad = 0;
-    pairs[pair_of[i]] = p;
+    pairs[kPairDfs ? nd.left_first >> 1 : pair_of[i]] = p;
 }
 
 struct Buf {
@@ -1124,7 +1124,10 @@ int flatten_bvh_device(const DeviceTree& t, uint32_t big_from, DeviceFlat& out, 
     BUILD_HIP(hipMemcpyAsync(&counts[0], pair_of.as<uint32_t>() + nn, 4, hipMemcpyDeviceToHost, st));
     BUILD_HIP(hipMemcpyAsync(&counts[1], big_of.as<uint32_t>() + nn, 4, hipMemcpyDeviceToHost, st));
     BUILD_HIP(hipStreamSynchronize(st));
+    if (kPairDfs) counts[0] = (nn + 1) / 2;  // records are indexed by left_first >> 1 < nn / 2
+    counts[0] += 1;                          // + 1: the record behind the last one may be touched (prefetch)
     BUILD_HIP(pairs.alloc((size_t)counts[0] * sizeof(PairRecord)));
+    BUILD_HIP(hipMemsetAsync(pairs.p, 0, (size_t)counts[0] * sizeof(PairRecord), st));
     BUILD_HIP(big_leaf.alloc((size_t)counts[1] * 8));
     hipLaunchKernelGGL(k_flatten, dim3(blocks(nn)), dim3(kBlock), 0, st, (const pt_bvh_node*)t.nodes, nn, pair_of.as<uint32_t>(), big_of.as<uint32_t>(), big_from,
                        pairs.as<PairRecord>(), big_leaf.as<uint32_t>(), root_ref.as<uint32_t>());

@@ -402,8 +402,15 @@ int flatten_bvh(const HostBVH& bvh, FlatBVH& out, uint32_t big_from) {
     std::vector<uint32_t> pair_of(nn, 0);
     uint32_t npairs = 0;
     for (size_t i = 0; i < nn; ++i)
-        if (bvh.nodes[i].count == 0) pair_of[i] = npairs++;
-    out.pairs.assign(npairs, PairRecord{});
+        if (bvh.nodes[i].count == 0) {
+            if (kPairDfs) {  // children pairs are disjoint, so left_first >> 1 is unique whatever numbering an adopted tree uses
+                pair_of[i] = bvh.nodes[i].left_first >> 1;
+                npairs = std::max(npairs, pair_of[i] + 1);
+            } else {
+                pair_of[i] = npairs++;
+            }
+        }
+    out.pairs.assign((size_t)npairs + 1, PairRecord{});  // + 1: the record behind the last one may be touched (prefetch)
     out.big_leaf.clear();
     auto make_ref = [&](uint32_t node) -> uint32_t {
         const pt_bvh_node& n = bvh.nodes[node];

@@ -45,6 +45,15 @@ constexpr uint64_t kMaxPrims = 1ull << 26;
 
 // One record per internal node: its two children, each as a 32-byte AABB node whose
 // (left_first, count) pair is replaced by (reference, 0).
+// Which record of `pairs` an internal node gets.  0: its rank among the internal nodes in node order.  1: its split event,
+// left_first >> 1 — the reference appends a node's children when it splits the node and splits depth first, left child
+// first (bvh.rs:52-62,87-97), so children are nodes 1 + 2e, 2 + 2e of split event e and records in event order are the
+// tree in DFS pre-order: the record after a node's is its left child's (or, below a leaf, the next subtree's).
+#ifndef PT_PAIR_DFS
+#define PT_PAIR_DFS 1
+#endif
+constexpr bool kPairDfs = PT_PAIR_DFS != 0;
+
 struct alignas(16) PairRecord {
     float lmin[3];
     uint32_t lref;

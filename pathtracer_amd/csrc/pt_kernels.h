@@ -24,6 +24,7 @@ struct DevScene {
     const uint32_t* lights;    // slots of emissive primitives
     uint32_t n_lights;
     uint32_t n_prims;
+    uint32_t n_pairs;          // records in `pairs` (one more is allocated behind them)
     uint32_t root_ref;
     uint32_t stack_cap;        // most entries a traversal can postpone (= tree levels - 1)
     float root_min[3], root_max[3];
@@ -32,6 +33,7 @@ struct DevScene {
     // nothing), and never when nee_literal is set (a light whose area or colour is not finite).  See shade_core.
     float nee_thr;
     uint32_t nee_literal;
+    uint32_t skip_repeated_miss;  // PT_OPT_SKIP_REPEATED_MISS (opt-in): see shade_core
 };
 
 // Paths a kernel without the NEE code could not finish (transport beyond nee_thr at a diffuse hit): their slots, for k_redo.

@@ -551,11 +551,10 @@ struct PhaseStats {
     }
 };
 
-// one internal-node step of one lane (bvh.rs:198-222): test both children, descend into the nearer, push the farther
+// one internal-node step of one lane (bvh.rs:198-222) on its node's record: test both children, descend into the nearer, push the farther
 template <bool COUNT>
-__device__ __forceinline__ void step_internal(const DevScene& S, LaneTrav& T, bool& active, const LaneStack& stk, uint32_t& nn, uint32_t& mine) {
-    const float4* rec = S.pairs + (size_t)T.cur * 4;
-    const float4 a = rec[0], b = rec[1], c = rec[2], e = rec[3];
+__device__ __forceinline__ void step_internal_on(float4 a, float4 b, float4 c, float4 e, LaneTrav& T, bool& active, const LaneStack& stk, uint32_t& nn,
+                                                 uint32_t& mine) {
     float tl, tr;
     const bool hl = slab(a.x, a.y, a.z, b.x, b.y, b.z, T.o, T.rcp, T.dist, &tl);
     const bool hr = slab(c.x, c.y, c.z, e.x, e.y, e.z, T.o, T.rcp, T.dist, &tr);
@@ -573,6 +572,41 @@ __device__ __forceinline__ void step_internal(const DevScene& S, LaneTrav& T, bo
     } else if (!lane_pop(T, stk)) {
         active = false;
     }
+}
+template <bool COUNT>
+__device__ __forceinline__ void step_internal(const DevScene& S, LaneTrav& T, bool& active, const LaneStack& stk, uint32_t& nn, uint32_t& mine) {
+    const float4* rec = S.pairs + (size_t)T.cur * 4;
+    const float4 a = rec[0], b = rec[1], c = rec[2], e = rec[3];
+    step_internal_on<COUNT>(a, b, c, e, T, active, stk, nn, mine);
+}
+
+#ifndef PT_DRAIN_GHOST
+#define PT_DRAIN_GHOST 0  // measured and not adopted (profiles/r3_ab_drained_read_ahead.txt): see below
+#endif
+// The internal step of a wave that is only emptying (k_path once the batch has no more paths to hand out): a handful of
+// long paths in a wave of idle lanes, every step a dependent fetch that pays a whole round trip to memory.  The pair records
+// are in split-event order, i.e. the tree in DFS pre-order (pt_bvh.h, PT_PAIR_DFS): behind a node's record come its left
+// child's, that one's children ... and near the leaves the whole subtree.  So the lanes that have nothing to do read ahead:
+// each takes the nearest traversing lane below it and fetches the record as many places behind that lane's as it is lanes
+// away, in the same load instruction as the real fetches.  Nothing is done with what they fetch — it is a prefetch into L1 /
+// L2, the visiting order is untouched — but the next steps of the traversal find their records there.
+// Result (round 3, A/B builds): nothing.  A blocking 1-spp call of C3 takes 9.5 ms with and without it, C4 11.3, C5 16.9, and
+// the 256-spp rates are equal: a wave that is emptying does not wait for pair records that miss (its few paths stay inside a
+// small part of the tree, which L2 holds); its ~2.6 k clocks per turn are the ~500 dependent instructions of a turn issued
+// by one wave alone on its SIMD, plus cache-hit latencies.  Kept as a build option for the record.
+template <bool COUNT>
+__device__ __forceinline__ void step_internal_readahead(const DevScene& S, LaneTrav& T, bool& active, bool at_internal, unsigned long long mi,
+                                                        const LaneStack& stk, uint32_t& nn, uint32_t& mine) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long below = mi & ((2ull << lane) - 1ull);  // traversing lanes at or below this one
+    const uint32_t owner = below ? 63u - (uint32_t)__clzll((long long)below) : 63u - (uint32_t)__clzll((long long)mi);
+    const uint32_t ahead = (lane - owner) & 63u;
+    const uint32_t cur_owner = (uint32_t)__shfl((int)T.cur, (int)owner, 64);
+    uint32_t idx = at_internal ? T.cur : cur_owner + ahead;
+    idx = idx < S.n_pairs ? idx : S.n_pairs - 1u;
+    const float4* rec = S.pairs + (size_t)idx * 4;
+    const float4 a = rec[0], b = rec[1], c = rec[2], e = rec[3];
+    if (at_internal) step_internal_on<COUNT>(a, b, c, e, T, active, stk, nn, mine);
 }
 
 // one primitive of a leaf against the lane's ray; an accepted hit replaces the previous one (last accepted wins)
@@ -921,6 +955,15 @@ __device__ __forceinline__ int shade_core(const DevScene& S, PathVals& pv, const
         transport = mul_ew(transport, (cos_i / mis) * brdf);
         it += 1;
         if (it >= depth) { radiance = acc; return SHADE_END; }
+        // Opt-in (PT_OPT_SKIP_REPEATED_MISS, never the default and never in a metric run): the reference now traces this very
+        // ray again (quirk Q3: the look-ahead hit is dropped, camera.rs:298-300 against :362).  If the look-ahead trace missed,
+        // ray.distance is still inf and the second traversal is the first one repeated — it misses again and the path ends
+        // in the sky (camera.rs:301-304).  Taking that result at once gives the same sums with one traversal less per such
+        // bounce; the executed-ray count then differs from the reference's by exactly those repeated misses.
+        if (S.skip_repeated_miss != 0u && !is_hit) {
+            radiance = acc + mul_ew(transport, 0.1f * sky_lookup(S, d));
+            return SHADE_END;
+        }
         // the next iteration re-traces this ray with the shortened ray.distance (quirk Q3)
         pv.tmax = t;
         pv.transport = transport;
@@ -1455,7 +1498,19 @@ __global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, c
                 st.lanes[4] += (unsigned long long)(__popcll(actv) + n_wait);
             }
 #endif
-            if (internal_turn || drained) {
+            if (PT_DRAIN_GHOST && kPairDfs && drained) {
+                const unsigned long long t0 = st.now();
+                if (mi) {  // (wave-uniform)
+                    step_internal_readahead<COUNT>(S, T, active, at_internal, mi, stk, nn, mine);
+#pragma unroll
+                    for (int rep = 1; rep < kInternalRepeat; ++rep) {
+                        const bool again = at_internal && active && !(T.cur & kLeafBit);
+                        const unsigned long long m2 = __ballot(again);
+                        if (m2) step_internal_readahead<COUNT>(S, T, active, again, m2, stk, nn, mine);
+                    }
+                }
+                st.add(2, mi, t0);
+            } else if (internal_turn || drained) {
                 const unsigned long long t0 = st.now();
                 if (at_internal) {
                     step_internal<COUNT>(S, T, active, stk, nn, mine);

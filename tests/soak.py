@@ -3,7 +3,10 @@
 Every round draws a scene (soup / statue / spheres of random size and materials, sometimes with a
 specular floor or a speculaty > 1 material so that shadow rays run), a camera, an image size, a
 depth and a sample count, and compares BVH, 20 000 traces (closest and any), camera state, and
-the frame sums in both pt_render modes and as queued one-sample calls (few and many, merged under a random cap).  Stops at the first difference (exit code 1)."""
+the frame sums in both pt_render modes and as queued one-sample calls (few and many, merged under a random cap).  Stops at the first difference (exit code 1).
+From round 3 the frame is compared with the loop AS WRITTEN (oracle nee_mode 0: the NEE block at every diffuse hit), and one scene in six gets
+colours that run the transport up to inf / NaN, so that the device's second, literal pass (k_redo) and its restart with the NEE kernels (random
+redo-list capacity) are part of the campaign."""
 import sys
 import time
 
@@ -50,6 +53,17 @@ def draw_scene(rng):
     return "spheres", scenes.default_scene()
 
 
+def spoil_colours(rng, scene):
+    """Colours that make transports overflow: a glass whose Beer factor is exp(+large), diffuse colours far above 1, a zero channel."""
+    mats = scene[-1].copy()
+    for m in mats:
+        if m["kind"] == scenes.MAT_DIELECTRIC and rng.random() < 0.7:
+            m["rgb"] = tuple(float(x) for x in rng.choice([0.5, 60.0, 300.0], size=3))
+        elif m["kind"] == scenes.MAT_DIFFUSE and rng.random() < 0.5:
+            m["rgb"] = tuple(float(x) for x in rng.choice([0.0, 0.9, 3e12, 2e19], size=3))
+    return scene[:-1] + (mats,)
+
+
 def main():
     minutes = float(sys.argv[1]) if len(sys.argv) > 1 else 3.0
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -57,12 +71,15 @@ def main():
     SCALE = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     sky = scenes.make_sky()
     t_end = time.time() + 60 * minutes
-    rounds = device_builds = 0
+    rounds = device_builds = redo_paths = redo_restarts = 0
     while time.time() < t_end:
         seed = seed0 + rounds
         rng = np.random.default_rng(seed)
         name, scene = draw_scene(rng)
+        if rng.random() < 1.0 / 6.0:
+            name, scene = name + "+spoilt", spoil_colours(rng, scene)
         g = ptcore.PathTracer(0).set_scene(scene, sky)
+        g.set_option(ptcore.OPT_REDO_CAPACITY, int(rng.choice([65536, 65536, 5, 0])))
         device_builds += int(g.build_info()[0])
         o = orc.from_scene(scene, sky)
         what = "bvh"
@@ -82,7 +99,7 @@ def main():
             W, H = int(rng.integers(1, 200 * SCALE)), int(rng.integers(1, 120 * SCALE))
             depth, spp = int(rng.choice([0, 1, 2, 5, 32])), int(rng.integers(1, 5))
             o.set_camera(co, ct, W, H)
-            o.render(spp, depth, seed=seed, nthreads=8, nee_mode=1)
+            o.render(spp, depth, seed=seed, nthreads=8, nee_mode=0)  # camera.rs:314-338 as written
             want = o.read_accum()[0]
             for mode in (1, 0):
                 g.set_option(ptcore.OPT_RENDER_MODE, mode)
@@ -109,13 +126,18 @@ def main():
                 g.render_async(1, depth, seed=seed)
             ok = ok and g.read_accum()[0].tobytes() == whole.tobytes()
             what += " %dx%d depth %d spp %d, %d queued calls" % (W, H, depth, spp, calls)
+        if ok and "render" in what:
+            c = g.counters()
+            redo_paths += int(c["redo_paths"])
+            redo_restarts += int(c["redo_restarts"])
         g.close()
         o.close()
         rounds += 1
         print(("ok   " if ok else "DIFF ") + "seed %d %s %s" % (seed, name, what), flush=True)
         if not ok:
             sys.exit(1)
-    print("soak: %d rounds (%d trees built on the GPU), no difference" % (rounds, device_builds))
+    print("soak: %d rounds (%d trees built on the GPU; %d paths finished by the literal second pass, %d batches run again with the NEE kernels), no difference"
+          % (rounds, device_builds, redo_paths, redo_restarts))
 
 
 if __name__ == "__main__":

@@ -480,6 +480,38 @@ def test_nee_block_runs_where_it_can_change_a_sum(ptcore, orc, sky, name):
         o.close()
 
 
+@pytest.mark.parametrize("name", ["spheres", "cube", "mesh_20k"])
+def test_opt_in_skip_of_the_repeated_miss_changes_no_sum(ptcore, pairs, name):
+    """PT_OPT_SKIP_REPEATED_MISS (opt-in, never in a metric run): a look-ahead trace that missed is not repeated by the next
+    iteration (quirk Q3 re-traces the same ray with ray.distance still inf: it can only miss again).  The frame is the oracle's
+    bit for bit in both schedulings; only the number of executed traversals drops — by the diffuse bounces that left the scene
+    (all of them in the sphere scene, where the re-trace is what ends every diffuse bounce in the sky)."""
+    g, o, scene, cam_o, cam_t = pairs[name]
+    W, H, spp = 160, 96, 3
+    o.set_camera(cam_o, cam_t, W, H)
+    o.reset_counters()
+    o.render(spp, 32, seed=61, nthreads=8, nee_mode=1)
+    want, oc = o.read_accum()[0].copy(), o.counters()
+    try:
+        for mode in (1, 0):
+            g.set_option(ptcore.OPT_RENDER_MODE, mode)
+            g.set_option(ptcore.OPT_SKIP_REPEATED_MISS, 1)
+            g.set_camera(cam_o, cam_t, W, H)
+            g.reset_counters()
+            g.render(spp, 32, seed=61)
+            assert g.read_accum()[0].tobytes() == want.tobytes(), mode
+            c = g.counters()
+            assert c["paths"] == oc["paths"] and c["rays_closest"] < oc["rays_closest"], (mode, c["rays_closest"], oc["rays_closest"])
+            g.set_option(ptcore.OPT_SKIP_REPEATED_MISS, 0)
+            g.set_camera(cam_o, cam_t, W, H)
+            g.reset_counters()
+            g.render(spp, 32, seed=61)
+            assert g.read_accum()[0].tobytes() == want.tobytes() and g.counters()["rays_closest"] == oc["rays_closest"]
+    finally:
+        g.set_option(ptcore.OPT_SKIP_REPEATED_MISS, 0)
+        g.set_option(ptcore.OPT_RENDER_MODE, 1)
+
+
 def test_sphere_lights_sampled_bit_exact(ptcore, orc, sky):
     """Sphere lights seen from a diffuse material with speculaty > 1: the shadow-ray block samples a point INSIDE the
     light (sphere.rs:98-118, radius * u.cbrt(), x and y both from cos(phi) as written), with cbrt from the shared

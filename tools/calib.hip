@@ -3,10 +3,12 @@
 //   gather64  one random 64-B record (4 x 16 B) per lane, every record of the table read exactly once,
 //             the access shape of k_path's node fetch           -> what FETCH_SIZE reports per gathered byte, and the
 //             rate at which HBM / Infinity Cache serve such gathers (the roof of the C5 soup)
+//   gather128 / gather256   the same with records of 2 / 4 ADJACENT 64-B sectors (aligned to their size): what a node record
+//             laid out next to the record visited after it would cost — the roof for that access shape (round 3)
 //   valu      independent plain fp32 v_mul / v_add (inline asm), 6 waves per SIMD -> VALU wave-instruction issue peak
 //   valu_pk   the same with packed v_pk_mul_f32 / v_pk_add_f32 (two operations per lane per instruction)
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o tools/calib tools/calib.hip
-// Run:   tools/calib <stream|gather64|valu|valu_pk> [MiB] [reps] [noflush]   (one JSON line per repetition; also under rocprofv3 --pmc FETCH_SIZE)
+// Run:   tools/calib <stream|gather64|gather128|gather256|valu|valu_pk> [MiB] [reps] [noflush]   (one JSON line per repetition; also under rocprofv3 --pmc FETCH_SIZE)
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -45,6 +47,26 @@ __global__ __launch_bounds__(64) void k_gather64(const float4* __restrict__ tabl
         const float4* p = table + (size_t)rec * 4;
         const float4 a = p[0], b = p[1], c = p[2], d = p[3];
         acc += a.x + b.y + c.z + d.w;
+    }
+    if (acc == 123.456f) out[0] = acc;
+}
+
+// S adjacent 64-B sectors per lane: one record of 64 * S bytes, aligned to its size, every record read exactly once
+template <int S>
+__global__ __launch_bounds__(64) void k_gather_adj(const float4* __restrict__ table, uint32_t n_records_log2, uint32_t per_lane, float* __restrict__ out) {
+    const uint32_t mask = (1u << n_records_log2) - 1u;
+    const uint32_t lanes = gridDim.x * blockDim.x;
+    const uint32_t me = blockIdx.x * blockDim.x + threadIdx.x;
+    float acc = 0.f;
+    for (uint32_t k = 0; k < per_lane; ++k) {
+        const uint32_t i = (k * lanes + me);
+        const uint32_t rec = (i * 2654435761u + 12345u) & mask;
+        const float4* p = table + (size_t)rec * (4 * S);
+        float4 v[4 * S];
+#pragma unroll
+        for (int j = 0; j < 4 * S; ++j) v[j] = p[j];
+#pragma unroll
+        for (int j = 0; j < 4 * S; ++j) acc += v[j].x + v[j].w;
     }
     if (acc == 123.456f) out[0] = acc;
 }
@@ -124,7 +146,9 @@ int main(int argc, char** argv) {
     size_t bytes = mib << 20;
     uint32_t log2rec = 0;
     while (((size_t)64 << (log2rec + 1)) <= bytes) ++log2rec;
-    if (!std::strcmp(what, "gather64")) bytes = (size_t)64 << log2rec;  // power-of-two record count
+    const int sectors = !std::strcmp(what, "gather128") ? 2 : !std::strcmp(what, "gather256") ? 4 : 1;
+    if (sectors > 1) log2rec -= sectors == 2 ? 1 : 2;  // records of 128 / 256 bytes
+    if (!std::strncmp(what, "gather", 6)) bytes = ((size_t)64 * sectors) << log2rec;  // power-of-two record count
     float4* buf = nullptr;
     CK(hipMalloc(&buf, bytes));
     CK(hipMemset(buf, 0, bytes));
@@ -141,15 +165,17 @@ int main(int argc, char** argv) {
         } else {
             const uint32_t n_rec = 1u << log2rec, lanes = 256 * 24 * 64;
             const uint32_t per_lane = n_rec / lanes;  // table sizes here are multiples of 24 MiB x 2^k only approximately: the rest is not read
-            hipLaunchKernelGGL(k_gather64, dim3(256 * 24), dim3(64), 0, 0, buf, log2rec, per_lane, out);
-            bytes = (size_t)per_lane * lanes * 64;
+            if (sectors == 2) hipLaunchKernelGGL(k_gather_adj<2>, dim3(256 * 24), dim3(64), 0, 0, buf, log2rec, per_lane, out);
+            else if (sectors == 4) hipLaunchKernelGGL(k_gather_adj<4>, dim3(256 * 24), dim3(64), 0, 0, buf, log2rec, per_lane, out);
+            else hipLaunchKernelGGL(k_gather64, dim3(256 * 24), dim3(64), 0, 0, buf, log2rec, per_lane, out);
+            bytes = (size_t)per_lane * lanes * 64 * sectors;
         }
         CK(hipEventRecord(b, 0));
         CK(hipEventSynchronize(b));
         float ms = 0;
         CK(hipEventElapsedTime(&ms, a, b));
-        std::printf("{\"kernel\": \"%s\", \"table_mib\": %zu, \"bytes_read\": %zu, \"ms\": %.3f, \"gb_per_s\": %.1f}\n", what, mib, bytes, ms,
-                    bytes / (ms * 1e-3) / 1e9);
+        std::printf("{\"kernel\": \"%s\", \"table_mib\": %zu, \"bytes_read\": %zu, \"ms\": %.3f, \"gb_per_s\": %.1f, \"g_records_per_s\": %.2f}\n", what, mib, bytes,
+                    ms, bytes / (ms * 1e-3) / 1e9, bytes / (64.0 * sectors) / (ms * 1e-3) / 1e9);
     }
     return 0;
 }
