@@ -24,15 +24,20 @@ Extra objects on the JSON line:
                `algorithmic` — they are served by L1 / L2 / Infinity Cache, so against the HBM peak they can
                exceed 1 and are NOT the headline.  The headline fraction is the highest roof fraction that can
                bind: `hbm` = fabric traffic per launch from rocprofv3 FETCH_SIZE / WRITE_SIZE passes
-               (profiles/r2_pmc.json, corrected as profiles/README.md states) / live kernel time / 8 TB/s, or
+               (profiles/r3_pmc.json, corrected as profiles/README.md states) / live kernel time / 8 TB/s, or
                `valu` = VALU wave-instructions per launch (SQ_INSTS_VALU pass) / live kernel time / the issue
                peak (1024 SIMDs x 2.4 GHz / 2 cycles); `lane_util` says how full those instructions were.
-               Kernel time is measured live with HIP events on the launching stream.
+               The headline object carries the three numbers side by side — `hbm_frac`, `valu_frac` and `lane_frac`
+               (= valu_frac x lane_util: the share of the lane-issue peak doing work) — with
+               `algorithmic_over_hbm_peak` (above 1: cache-served).  Kernel time is measured live with HIP events on the
+               launching stream; the counters cannot be read inside an ordinary run (they need rocprofv3 passes) and come
+               from the committed passes over this very command (`pmc_source`), per launch.
   cpu_baseline the CPU oracle (a C++ restatement of the reference, kind "port") in the reference's
                threading mode on this box's host cores, on a bounded sample of the same workload.
   cpu_configs  BASELINE configs[0] (C1: sphere scene 512x512, 1 spp per frame) on the CPU path, with the
                GPU's rate on the same frames beside it.
   spp_sweep    Mrays/s at 1 / 8 / 64 samples per call, calls queued with pt_render_async (and 1 spp blocking).
+  opt_in       options that are never part of the metric run, each with its own rate (PT_OPT_SKIP_REPEATED_MISS: Mpaths/s).
 """
 import argparse
 import json
@@ -49,7 +54,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_GWIPS = 1024 * 2.4 / 2  # 256 CUs x 4 SIMDs, one plain wave64 VALU instruction per 2 cycles at 2.4 GHz (MI355X_MICROARCH.md: v_fma_f32 wave64
                                  # 2 cyc; tools/calib.hip measures 1051 G/s at the clock the chip holds) = 1228.8 G wave-inst/s
-PMC_FILE = os.path.join(ROOT, "profiles", "r2_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r3_pmc.json")  # counters of the round-3 kernels (tools/profile_round.sh, tools/make_pmc_json.py)
 
 
 def parse_args():
@@ -221,6 +226,29 @@ def spp_sweep(g, ptcore, W, H, depth, seed):
     dt = time.perf_counter() - t0
     c = g.counters()
     out["1_spp_per_call_blocking"] = {"mrays_per_s": (c["rays_closest"] + c["rays_any"]) / dt / 1e6, "ms_per_call": dt * 1e3 / 16, "calls": 16}
+    return out
+
+
+def opt_in_entry(g, ptcore, spp, depth, seed):
+    """Options that are never part of the metric run, each with its own line.  skip_repeated_miss: PT_OPT_SKIP_REPEATED_MISS — the same frame bit
+    for bit, but a look-ahead trace that missed is not traced a second time (quirk Q3's re-trace), so fewer traversals are EXECUTED: compare
+    Mpaths/s with the headline's, not Mrays/s (the ray count is no longer the reference's)."""
+    out = {}
+    g.set_option(ptcore.OPT_SKIP_REPEATED_MISS, 1)
+    try:
+        g.reset_accum()
+        g.render(spp, depth, seed)
+        g.reset_counters()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            g.render(spp, depth, seed)
+        dt = time.perf_counter() - t0
+        c = g.counters()
+        out["skip_repeated_miss"] = {"mpaths_per_s": c["paths"] / dt / 1e6, "mrays_executed_per_s": (c["rays_closest"] + c["rays_any"]) / dt / 1e6,
+                                     "rays_executed_per_path": (c["rays_closest"] + c["rays_any"]) / max(c["paths"], 1), "ms_per_step": dt * 1e3 / 2, "spp_per_step": spp,
+                                     "note": "same sums as the metric run; NOT the metric: executed traversals differ from the reference's"}
+    finally:
+        g.set_option(ptcore.OPT_SKIP_REPEATED_MISS, 0)
     return out
 
 
@@ -426,21 +454,25 @@ def main():
                     roof["fabric_gather"] = {"achieved": req, "peak": peak_ic, "unit": "G 64-B read requests/s", "frac": req / peak_ic,
                                              "peak_hbm_resident": cal["fabric_gather_peak_g_requests_per_s_hbm"], "l2_hit_rate": pmc["l2_hit_rate"],
                                              "note": "L2-miss read requests (TCC_EA0_RDREQ) per second against the rate a pure random 64-B-record gather reaches on "
-                                                     "this GPU (tools/calib.hip, profiles/r2_calib.json: table resident in the Infinity Cache / in HBM only). "
+                                                     "this GPU (tools/calib.hip, profiles/r3_calib.json: table resident in the Infinity Cache / in HBM only). "
                                                      "A MEASURED peak, not a spec figure, so it is reported beside the headline, not as it"}
                 roof["traffic"] = pmc["hbm_bytes_per_launch"]
-                roof["pmc_source"] = pmc.get("source", "profiles/r2_pmc.json")
+                roof["pmc_source"] = pmc.get("source", "profiles/r3_pmc.json")
                 top = "valu" if valu_frac >= hbm_frac else "hbm"
                 roof.update({"bound": top, "achieved": roof[top]["achieved"], "peak": roof[top]["peak"], "unit": roof[top]["unit"],
-                             "frac": roof[top]["frac"]})
+                             "frac": roof[top]["frac"], "hbm_frac": hbm_frac, "valu_frac": valu_frac, "lane_frac": valu_frac * pmc["lane_util"],
+                             "algorithmic_over_hbm_peak": alg_gbs / HBM_PEAK_GBS,
+                             "note": "frac = the larger of hbm_frac (fabric bytes / 8 TB/s) and valu_frac (VALU wave-instructions / issue peak); lane_frac = valu_frac x "
+                                     "active lanes per instruction; algorithmic_over_hbm_peak > 1 because most of the bytes the algorithm asks for are served by caches"})
             else:
                 roof.update({"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                             "note": "no PMC passes committed for this configuration (profiles/r2_pmc.json): only the algorithmic figure is live"})
+                             "note": "no PMC passes committed for this configuration (profiles/r3_pmc.json): only the algorithmic figure is live"})
             out["roofline"] = roof
             if args.mode != "path":
                 out["tail"] = {"share_of_rays": alg["tail_share"], "launches": c["tail_launches"], "ms_busy": c["tail_ms"]}
         if world == 1 and not args.no_extras:
             out["spp_sweep"] = spp_sweep(g, ptcore, W, H, args.depth, seed)
+            out["opt_in"] = opt_in_entry(g, ptcore, spp, args.depth, seed)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, sky, cam_o, cam_t, W, H, args.depth)
             if not args.no_extras:

@@ -1,15 +1,17 @@
-"""Collects the round-2 evidence under gpurun_out/r2/ into profiles/ (tracked):
+"""Collects a round's evidence under gpurun_out/<round>/ into profiles/ (tracked); round = $ROUND, default r3:
   profiles/r2_<tag>_{bench.json,kernel_stats.csv,pmc_k_path.json}   per profiled workload (tools/profile_r2.sh)
   profiles/r2_calib.json                                           calibration of FETCH_SIZE and of the VALU issue peak (tools/calib_r2.sh)
   profiles/r2_pmc.json                                             what bench.py reads: per-launch counters of k_path keyed workload:mode:spp:depth
-usage: python3 tools/make_pmc_json.py tag=WORKLOAD:SPP ..."""
+  profiles/<round>_pmc_table.md                                     the same numbers as the table DESIGN.md / profiles/README.md quote (generated, never typed)
+usage: ROUND=r3 python3 tools/make_pmc_json.py tag=WORKLOAD:SPP ..."""
 import json
 import os
 import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "r2")
+RND = os.environ.get("ROUND", "r3")
+SRC = os.path.join(ROOT, "gpurun_out", RND)
 DST = os.path.join(ROOT, "profiles")
 
 
@@ -49,34 +51,63 @@ def calib():
                                                      "FETCH_SIZE_bytes": p_mall["FETCH_SIZE"] * 1024,
                                                      "fetch_size_over_bytes": p_mall["FETCH_SIZE"] * 1024 / g_mall[0]["bytes_read"],
                                                      "g_requests_per_s": best(g_mall[1:], "gb_per_s") / 64},
+        "gather_adjacent_sectors": {k: {"hbm_4GiB_g_records_per_s": best(lines(f"{k}_hbm.txt"), "g_records_per_s"), "hbm_4GiB_gb_per_s": best(lines(f"{k}_hbm.txt"), "gb_per_s"),
+                                         "infinity_cache_128MiB_g_records_per_s": best(lines(f"{k}_mall.txt")[1:], "g_records_per_s"),
+                                         "infinity_cache_128MiB_gb_per_s": best(lines(f"{k}_mall.txt")[1:], "gb_per_s")}
+                                    for k in ("gather128", "gather256") if os.path.exists(os.path.join(c, f"{k}_hbm.txt"))},
         "valu_issue_plain": valu_entry(valu, p_valu, p_clk, "independent v_mul_f32 / v_add_f32 (inline asm), 6144 waves = 6 per SIMD"),
         "valu_issue_packed": valu_entry(valu_pk, p_valu_pk, p_pk_clk, "the same with v_pk_mul_f32 / v_pk_add_f32 (two fp32 operations per lane per instruction)"),
     }
-    json.dump(out, open(os.path.join(DST, "r2_calib.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(DST, f"{RND}_calib.json"), "w"), indent=1)
     return out
+
+
+def write_table(table):
+    """profiles/<round>_pmc_table.md: per workload, what the counters and the bench line of the same profiling run say."""
+    cal = table.get("_calibration", {})
+    rows = ["| workload | Grays/s | k_path ms per launch | node tests / ray | prim tests / ray | algorithmic GB per launch (over HBM peak) | fabric GB per launch | HBM frac | L2 hit | L2-miss requests G/s (of the gather rate) | VALU G wave-inst/s (frac) | lanes active | lane frac | waves waiting |",
+            "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
+    for key in sorted(k for k in table if not k.startswith("_")):
+        p = table[key]
+        wl, _, spp, _ = key.split(":")
+        tag = p["source"].split("_")[1]
+        b = json.load(open(os.path.join(DST, f"{RND}_{tag}_bench.json")))
+        r = b["roofline"]
+        ms = r["kernel_busy_ms"] / r["launches"]
+        hbm = p["hbm_bytes_per_launch"] / ms / 1e6
+        req = p["ea_read_requests_per_launch"] / ms / 1e6
+        peak = cal.get("fabric_gather_peak_g_requests_per_s_hbm" if wl == "C5" else "fabric_gather_peak_g_requests_per_s_infinity_cache", float("nan"))
+        valu = p["valu_wave_insts_per_launch"] / ms / 1e6
+        rows.append(f"| {wl} ({spp} spp / launch) | {b['value'] / 1e3:.2f} | {ms:.1f} | {r['algorithmic']['node_tests_per_ray']:.1f} | {r['algorithmic']['prim_tests_per_ray']:.2f} | "
+                    f"{r['algorithmic']['bytes_per_launch'] / 1e9:.0f} ({r['algorithmic']['over_hbm_peak']:.2f}) | {p['hbm_bytes_per_launch'] / 1e9:.1f} | {hbm / 8000:.2f} | "
+                    f"{p['l2_hit_rate']:.2f} | {req:.1f} ({req / peak:.2f} of {'HBM' if wl == 'C5' else 'Infinity-Cache'}-resident {peak:.1f}) | {valu:.0f} ({valu / 1228.8:.2f}) | "
+                    f"{p['lane_util']:.2f} | {valu / 1228.8 * p['lane_util']:.2f} | {p['wave_wait_any_frac']:.2f} |")
+    head = (f"Generated by tools/make_pmc_json.py from profiles/{RND}_pmc.json and profiles/{RND}_<tag>_bench.json (one profiling run per workload: bench line, rocprofv3 kernel stats "
+            f"and one --pmc pass per counter group of the same command).  Rates use the live kernel time of that run's bench line.\n\n")
+    open(os.path.join(DST, f"{RND}_pmc_table.md"), "w").write(head + "\n".join(rows) + "\n")
 
 
 def main():
     cal = calib()
-    path = os.path.join(DST, "r2_pmc.json")
+    path = os.path.join(DST, f"{RND}_pmc.json")
     table = json.load(open(path)) if os.path.exists(path) else {}
     for arg in sys.argv[1:]:
         tag, rest = arg.split("=")
         wl, spp = rest.split(":")
         d = os.path.join(SRC, tag)
         p = json.load(open(os.path.join(d, "pmc.json")))
-        shutil.copy(os.path.join(d, "pmc.json"), os.path.join(DST, f"r2_{tag}_pmc_k_path.json"))
-        shutil.copy(os.path.join(d, "bench.json"), os.path.join(DST, f"r2_{tag}_bench.json"))
+        shutil.copy(os.path.join(d, "pmc.json"), os.path.join(DST, f"{RND}_{tag}_pmc_k_path.json"))
+        shutil.copy(os.path.join(d, "bench.json"), os.path.join(DST, f"{RND}_{tag}_bench.json"))
         if os.path.exists(os.path.join(d, "kernel_stats.csv")):
-            shutil.copy(os.path.join(d, "kernel_stats.csv"), os.path.join(DST, f"r2_{tag}_kernel_stats.csv"))
+            shutil.copy(os.path.join(d, "kernel_stats.csv"), os.path.join(DST, f"{RND}_{tag}_kernel_stats.csv"))
         fetch, write = p["fetch"]["FETCH_SIZE"] * 1024, p["write"]["WRITE_SIZE"] * 1024
         sq1, sq2, tcc, grbm = p["sq1"], p["sq2"], p["tcc"], p["grbm"]
         table[f"{wl}:path:{spp}:32"] = {
-            "source": f"profiles/r2_{tag}_pmc_k_path.json (tools/profile_r2.sh {tag} {wl} {spp}: one rocprofv3 --pmc pass per counter group over `bench.py --steps 1 --warmup 1`)",
+            "source": f"profiles/{RND}_{tag}_pmc_k_path.json (tools/profile_round.sh {tag} {wl} {spp}: one rocprofv3 --pmc pass per counter group over `bench.py --steps 1 --warmup 1`)",
             "kernel_ms_under_pmc": sq1["dur_ms"],
             "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write,
             "hbm_note": "FETCH_SIZE + WRITE_SIZE (KiB x 1024) per k_path launch.  FETCH_SIZE = TCC_EA0_RDREQ x 64 B; for this kernel's read shape (one 64-B-aligned "
-                        "record per lane) profiles/r2_calib.json shows it reads the bytes exactly (ratio 1.00; the x2 of MI355X_MICROARCH.md applies to wide "
+                        "record per lane) profiles/" + RND + "_calib.json shows it reads the bytes exactly (ratio 1.00; the x2 of MI355X_MICROARCH.md applies to wide "
                         "streaming reads, ratio 0.50 there), so no correction is applied.  These are L2-miss requests to the fabric: Infinity-Cache hits are "
                         "included, HBM itself carries at most this.",
             "ea_read_requests_per_launch": tcc["TCC_EA0_RDREQ_sum"],
@@ -93,8 +124,9 @@ def main():
                                  "valu_plain_measured_g_wave_insts_per_s": cal["valu_issue_plain"]["g_wave_insts_per_s_best"],
                                  "valu_plain_simd_cycles_per_wave_inst": cal["valu_issue_plain"]["simd_cycles_per_wave_inst_under_pmc"],
                                  "valu_packed_simd_cycles_per_wave_inst": cal["valu_issue_packed"]["simd_cycles_per_wave_inst_under_pmc"],
-                                 "source": "profiles/r2_calib.json"}
+                                 "source": f"profiles/{RND}_calib.json"}
     json.dump(table, open(path, "w"), indent=1, sort_keys=True)
+    write_table(table)
     print(json.dumps(table, indent=1)[:3000])
 
 
