@@ -85,6 +85,13 @@ def write_table(table):
     head = (f"Generated by tools/make_pmc_json.py from profiles/{RND}_pmc.json and profiles/{RND}_<tag>_bench.json (one profiling run per workload: bench line, rocprofv3 kernel stats "
             f"and one --pmc pass per counter group of the same command).  Rates use the live kernel time of that run's bench line.\n\n")
     open(os.path.join(DST, f"{RND}_pmc_table.md"), "w").write(head + "\n".join(rows) + "\n")
+    # the same table between the markers of the documents that quote it
+    for doc in (os.path.join(DST, "README.md"), os.path.join(ROOT, "DESIGN.md")):
+        text = open(doc).read()
+        a, b = text.find("<!-- pmc-table:begin -->"), text.find("<!-- pmc-table:end -->")
+        if a >= 0 and b > a:
+            text = text[:a] + "<!-- pmc-table:begin -->\n" + f"(generated from profiles/{RND}_pmc.json by tools/make_pmc_json.py)\n\n" + "\n".join(rows) + "\n" + text[b:]
+            open(doc, "w").write(text)
 
 
 def main():
