@@ -70,6 +70,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-replay", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the spp sweep and the C1 entry")
+    ap.add_argument("--blocking-steps", action="store_true", help="pt_render (wait after every step) instead of pt_render_async + one pt_wait")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N > 1 path on ONE GPU (all ranks on device 0, collectives staged through the host)")
     ap.add_argument("--verify", action="store_true", help="rank 0 re-renders the combined frame alone (untimed) and compares")
@@ -303,8 +304,16 @@ def main():
         return ptcore.Shard(ptcore.SHARD_ALL, 0, 1, 0, ptdist.sample_begin(step, rank, world, spp))
 
     def run_steps(first, count, flags):
+        # The steps are submitted the way the library is meant to be driven (pt_render_async, one pt_wait at the end of the
+        # region): step k + 1 starts on the device while the last long paths of step k finish, as for any queued calls
+        # (DESIGN section 6).  Every step is still its own launch of `spp` samples (531 M paths of C3 are above the merge cap),
+        # all K are complete when the timed region ends.  --blocking-steps waits after every step instead.
         for s in range(first, first + count):
-            g.render(spp, args.depth, seed, shard_for(s), flags)
+            if args.blocking_steps:
+                g.render(spp, args.depth, seed, shard_for(s), flags)
+            else:
+                g.render_async(spp, args.depth, seed, shard_for(s), flags)
+        g.wait()
 
     def combine():
         if not use_dist:
@@ -403,6 +412,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max * 1e3 / max(args.steps, 1),
             "higher_is_better": True, "scaling": "strong" if tiles else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "spp_per_step": spp, "max_depth": args.depth, "parallelism": par,
+                       "steps_submitted": "blocking (pt_render)" if args.blocking_steps else "queued (pt_render_async per step, one pt_wait)",
                        "paths_per_step_per_gpu": (W * H * spp) // (world if tiles else 1)},
             "mpaths_per_s": paths_all / dt_max / 1e6,
             "rays_per_path": rays_all / max(paths_all, 1),
