@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -100,19 +101,19 @@ struct RenderJob {
 // hipGetSymbolAddress: the device address is resolved once per device in pt_create (g_scratch_ptr)
 // and only that pointer is ever handed to kernels or copies.
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
-static unsigned char* g_scratch_ptr[kMaxDevices] = {};
+static std::atomic<unsigned char*> g_scratch_ptr[kMaxDevices] = {};  // (contexts may be created from several host threads)
 
 // with `device` current: the address of this device's copy of `scratch`
 static hipError_t resolve_scratch(int device, unsigned char** out) {
     if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
-    if (!g_scratch_ptr[device]) {
-        unsigned char* p = nullptr;
+    unsigned char* p = g_scratch_ptr[device].load(std::memory_order_acquire);
+    if (!p) {
         hipError_t e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
         if (e != hipSuccess) return e;
         if (!p) return hipErrorInvalidSymbol;
-        g_scratch_ptr[device] = p;
+        g_scratch_ptr[device].store(p, std::memory_order_release);  // every thread resolves the same address
     }
-    *out = g_scratch_ptr[device];
+    *out = p;
     return hipSuccess;
 }
 
