@@ -462,9 +462,11 @@ def main():
                     req = pmc["ea_read_requests_per_launch"] / (ms_per_launch * 1e-3) / 1e9
                     peak_ic = cal["fabric_gather_peak_g_requests_per_s_infinity_cache"]
                     roof["fabric_gather"] = {"achieved": req, "peak": peak_ic, "unit": "G 64-B read requests/s", "frac": req / peak_ic,
-                                             "peak_hbm_resident": cal["fabric_gather_peak_g_requests_per_s_hbm"], "l2_hit_rate": pmc["l2_hit_rate"],
+                                             "peak_hbm_resident": cal["fabric_gather_peak_g_requests_per_s_hbm"], "frac_of_hbm_resident_peak": req / cal["fabric_gather_peak_g_requests_per_s_hbm"],
+                                             "l2_hit_rate": pmc["l2_hit_rate"],
                                              "note": "L2-miss read requests (TCC_EA0_RDREQ) per second against the rate a pure random 64-B-record gather reaches on "
-                                                     "this GPU (tools/calib.hip, profiles/r3_calib.json: table resident in the Infinity Cache / in HBM only). "
+                                                     "this GPU (tools/calib.hip, profiles/r3_calib.json: table resident in the Infinity Cache (frac) / a 1-GiB table in HBM (frac_of_hbm_resident_peak: the one "
+                                                     "that applies to C5, whose working set does not fit the cache); tables of 4 GiB and more gather at 19 G/s only). "
                                                      "A MEASURED peak, not a spec figure, so it is reported beside the headline, not as it"}
                 roof["traffic"] = pmc["hbm_bytes_per_launch"]
                 roof["pmc_source"] = pmc.get("source", "profiles/r3_pmc.json")

@@ -108,3 +108,22 @@ def test_only_p_or_no_key_does_not_count_as_a_change():
     assert res.returncode == 0
     lines = [ln for ln in res.stdout.splitlines() if not ln.startswith("origin:")]
     assert [ln.split()[0] for ln in lines] == ["0", "0"]
+
+
+def test_render_refuses_more_ranks_than_devices():
+    """`render --gpus N` (the native multi-GPU host, pathtracer_amd/host/multi_gpu.hpp) says so at once, with a non-zero exit,
+    when N exceeds the visible devices — before it loads or builds anything.  Here: whatever this machine has, plus one."""
+    import os
+    import subprocess
+    render = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pathtracer_amd", "host", "render")
+    assert os.path.exists(render), "pathtracer_amd/host/render is not built"
+    import torch
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([render, "--gpus", str(n)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 3 and "visible" in r.stderr
+    r = subprocess.run([render, "--gpus", "1", "--shard", "rows"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2
+    libs = subprocess.run(["ldd", render], capture_output=True, text=True).stdout
+    assert "librccl" in libs   # the collective is linked into the host program ...
+    core = os.path.join(os.path.dirname(render), "..", "libptcore.so")
+    assert "librccl" not in subprocess.run(["ldd", core], capture_output=True, text=True).stdout   # ... not into the library

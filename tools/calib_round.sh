@@ -10,6 +10,8 @@ C=$R/tools/calib
 timeout -k 10 120 $C stream 4096 3 > $O/stream.txt 2>&1 || { cat $O/stream.txt; exit 1; }
 timeout -k 10 120 $C gather64 4096 3 > $O/gather_hbm.txt 2>&1 || exit 1
 timeout -k 10 120 $C gather64 128 6 noflush > $O/gather_mall.txt 2>&1 || exit 1
+# the rate against the table size: HBM-resident tables up to 2 GiB gather at 34 - 36 G records/s, from 4 GiB on at 19 (a cliff, not a slope)
+for m in 512 1024 2048 4096 8192 16384; do timeout -k 10 120 $C gather64 $m 3 | tail -1; done > $O/gather_sizes.txt 2>&1 || exit 1
 for k in gather128 gather256; do timeout -k 10 120 $C $k 4096 3 > $O/${k}_hbm.txt 2>&1 || exit 1; timeout -k 10 120 $C $k 128 6 noflush > $O/${k}_mall.txt 2>&1 || exit 1; done
 timeout -k 10 120 $C valu 0 3 > $O/valu.txt 2>&1 || exit 1
 timeout -k 10 120 $C valu_pk 0 3 > $O/valu_pk.txt 2>&1 || exit 1

@@ -51,6 +51,8 @@ def calib():
                                                      "FETCH_SIZE_bytes": p_mall["FETCH_SIZE"] * 1024,
                                                      "fetch_size_over_bytes": p_mall["FETCH_SIZE"] * 1024 / g_mall[0]["bytes_read"],
                                                      "g_requests_per_s": best(g_mall[1:], "gb_per_s") / 64},
+        "gather_64B_records_by_table_size": {str(r["table_mib"]) + "MiB": {"g_requests_per_s": r["g_records_per_s"], "gb_per_s": r["gb_per_s"]}
+                                             for r in (lines("gather_sizes.txt") if os.path.exists(os.path.join(c, "gather_sizes.txt")) else [])},
         "gather_adjacent_sectors": {k: {"hbm_4GiB_g_records_per_s": best(lines(f"{k}_hbm.txt"), "g_records_per_s"), "hbm_4GiB_gb_per_s": best(lines(f"{k}_hbm.txt"), "gb_per_s"),
                                          "infinity_cache_128MiB_g_records_per_s": best(lines(f"{k}_mall.txt")[1:], "g_records_per_s"),
                                          "infinity_cache_128MiB_gb_per_s": best(lines(f"{k}_mall.txt")[1:], "gb_per_s")}
@@ -80,7 +82,7 @@ def write_table(table):
         valu = p["valu_wave_insts_per_launch"] / ms / 1e6
         rows.append(f"| {wl} ({spp} spp / launch) | {b['value'] / 1e3:.2f} | {ms:.1f} | {r['algorithmic']['node_tests_per_ray']:.1f} | {r['algorithmic']['prim_tests_per_ray']:.2f} | "
                     f"{r['algorithmic']['bytes_per_launch'] / 1e9:.0f} ({r['algorithmic']['over_hbm_peak']:.2f}) | {p['hbm_bytes_per_launch'] / 1e9:.1f} | {hbm / 8000:.2f} | "
-                    f"{p['l2_hit_rate']:.2f} | {req:.1f} ({req / peak:.2f} of {'HBM' if wl == 'C5' else 'Infinity-Cache'}-resident {peak:.1f}) | {valu:.0f} ({valu / 1228.8:.2f}) | "
+                    f"{p['l2_hit_rate']:.2f} | {req:.1f} ({req / peak:.2f} of {'HBM-resident (1-GiB table)' if wl == 'C5' else 'Infinity-Cache-resident'} {peak:.1f}) | {valu:.0f} ({valu / 1228.8:.2f}) | "
                     f"{p['lane_util']:.2f} | {valu / 1228.8 * p['lane_util']:.2f} | {p['wave_wait_any_frac']:.2f} |")
     head = (f"Generated by tools/make_pmc_json.py from profiles/{RND}_pmc.json and profiles/{RND}_<tag>_bench.json (one profiling run per workload: bench line, rocprofv3 kernel stats "
             f"and one --pmc pass per counter group of the same command).  Rates use the live kernel time of that run's bench line.\n\n")
@@ -127,7 +129,10 @@ def main():
         }
     if cal:
         table["_calibration"] = {"fabric_gather_peak_g_requests_per_s_infinity_cache": cal["gather_64B_records_infinity_cache_128MiB"]["g_requests_per_s"],
-                                 "fabric_gather_peak_g_requests_per_s_hbm": cal["gather_64B_records_hbm_4GiB"]["g_requests_per_s"],
+                                 # HBM-resident working sets here are 1 - 2 GiB (C5: 1.4 GB): the rate of a 1-GiB table, not of the 4-GiB one behind
+                                 # the cliff (19 G/s) that round 2 used
+                                 "fabric_gather_peak_g_requests_per_s_hbm": cal["gather_64B_records_by_table_size"].get("1024MiB", cal["gather_64B_records_hbm_4GiB"])["g_requests_per_s"],
+                                 "fabric_gather_peak_g_requests_per_s_hbm_tables_of_4GiB_and_more": cal["gather_64B_records_hbm_4GiB"]["g_requests_per_s"],
                                  "valu_plain_measured_g_wave_insts_per_s": cal["valu_issue_plain"]["g_wave_insts_per_s_best"],
                                  "valu_plain_simd_cycles_per_wave_inst": cal["valu_issue_plain"]["simd_cycles_per_wave_inst_under_pmc"],
                                  "valu_packed_simd_cycles_per_wave_inst": cal["valu_issue_packed"]["simd_cycles_per_wave_inst_under_pmc"],
