@@ -37,6 +37,24 @@ namespace pt {
 __device__ __forceinline__ V3 xyz(float4 v) { return V3{v.x, v.y, v.z}; }
 __device__ __forceinline__ V3 ld3(const float* p) { return V3{p[0], p[1], p[2]}; }
 
+// Node and triangle records through buffer loads (PT_BUFFER_LOADS): the record's byte offset is ONE 32-bit shift of its index
+// (records are 64 B, at most 2^26 of them: the offset fits 32 bits) and the base lives in a scalar resource descriptor, where
+// a flat global load needs a 64-bit shift and a 64-bit add per record — quarter-rate instructions — in the hottest loop.
+#ifndef PT_BUFFER_LOADS
+#define PT_BUFFER_LOADS 1  // C3 +4.5 %, C4 +3.3 %, C5 +4.1 % (profiles/r3_ab_buffer_loads.txt)
+#endif
+#if PT_BUFFER_LOADS
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t record_rsrc(const float4* base, uint32_t n_records) {
+    const unsigned long long bytes = (unsigned long long)n_records * 64ull;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes > 0xffffffffull ? (int)0xffffffffu : (int)(uint32_t)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 record_quad(__amdgpu_buffer_rsrc_t r, uint32_t index, int quad) {
+    const f4v v = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(r, (int)(index << 6) + 16 * quad, 0, 0));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // Per-lane traversal stack: the first kLdsStack levels live in LDS laid out [level][thread] so that
 // a wave's accesses hit 64 consecutive 8-byte words whatever level each lane is at (no bank
@@ -87,8 +105,13 @@ __device__ __forceinline__ void traverse(const DevScene& S, V3 o, V3 d, float& d
     while (true) {
         bool need_pop;
         if (!(cur & kLeafBit)) {
+#if PT_BUFFER_LOADS
+            const __amdgpu_buffer_rsrc_t rp = record_rsrc(S.pairs, S.n_pairs + 1u);
+            const float4 a = record_quad(rp, cur, 0), b = record_quad(rp, cur, 1), c = record_quad(rp, cur, 2), e = record_quad(rp, cur, 3);
+#else
             const float4* rec = S.pairs + (size_t)cur * 4;
             const float4 a = rec[0], b = rec[1], c = rec[2], e = rec[3];
+#endif
             float tl, tr;
             const bool hl = slab(a.x, a.y, a.z, b.x, b.y, b.z, o, rcp, dist, &tl);
             const bool hr = slab(c.x, c.y, c.z, e.x, e.y, e.z, o, rcp, dist, &tr);
@@ -120,8 +143,13 @@ __device__ __forceinline__ void traverse(const DevScene& S, V3 o, V3 d, float& d
                 const uint32_t slot = first + k;
                 if (COUNT) n_prim_tests += 1;  // per call: intersect_any leaves the leaf at its first hit (bvh.rs:246-248)
                 if (PRIM == PRIM_TRIANGLE) {
+#if PT_BUFFER_LOADS
+                    const __amdgpu_buffer_rsrc_t rt = record_rsrc(S.prim, S.n_prims);
+                    const float4 a = record_quad(rt, slot, 0), b = record_quad(rt, slot, 1), c = record_quad(rt, slot, 2);
+#else
                     const float4* tp = S.prim + (size_t)slot * kTriStride;
                     const float4 a = tp[0], b = tp[1], c = tp[2];
+#endif
                     float t, u, v, det;
                     if (tri_hit(V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, V3{b.z, b.w, c.x}, o, d, &t, &u, &v, &det)) {
                         dist = t;  // unconditionally, triangle.rs:72
@@ -575,8 +603,13 @@ __device__ __forceinline__ void step_internal_on(float4 a, float4 b, float4 c, f
 }
 template <bool COUNT>
 __device__ __forceinline__ void step_internal(const DevScene& S, LaneTrav& T, bool& active, const LaneStack& stk, uint32_t& nn, uint32_t& mine) {
+#if PT_BUFFER_LOADS
+    const __amdgpu_buffer_rsrc_t rp = record_rsrc(S.pairs, S.n_pairs + 1u);
+    const float4 a = record_quad(rp, T.cur, 0), b = record_quad(rp, T.cur, 1), c = record_quad(rp, T.cur, 2), e = record_quad(rp, T.cur, 3);
+#else
     const float4* rec = S.pairs + (size_t)T.cur * 4;
     const float4 a = rec[0], b = rec[1], c = rec[2], e = rec[3];
+#endif
     step_internal_on<COUNT>(a, b, c, e, T, active, stk, nn, mine);
 }
 
@@ -613,8 +646,14 @@ __device__ __forceinline__ void step_internal_readahead(const DevScene& S, LaneT
 template <int PRIM>
 __device__ __forceinline__ void test_prim(const DevScene& S, LaneTrav& T, uint32_t ps) {
     if (PRIM == PRIM_TRIANGLE) {
+#if PT_BUFFER_LOADS
+        static_assert(kTriStride == 4, "buffer loads address 64-byte triangle slots");
+        const __amdgpu_buffer_rsrc_t rt = record_rsrc(S.prim, S.n_prims);
+        const float4 a = record_quad(rt, ps, 0), b = record_quad(rt, ps, 1), c = record_quad(rt, ps, 2);
+#else
         const float4* tp = S.prim + (size_t)ps * kTriStride;
         const float4 a = tp[0], b = tp[1], c = tp[2];
+#endif
         float t, u, v, det;
         if (tri_hit(V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, V3{b.z, b.w, c.x}, T.o, T.d, &t, &u, &v, &det)) {
             T.dist = t;  // unconditionally, triangle.rs:72
@@ -714,8 +753,13 @@ __device__ __forceinline__ void step_prim_wave(const DevScene& S, LaneTrav& T, b
             float t = 0.f, u = 0.f, v = 0.f, det = 0.f;
             bool hit = false;
             if (k < n) {
+#if PT_BUFFER_LOADS
+                const __amdgpu_buffer_rsrc_t rt = record_rsrc(S.prim, S.n_prims);
+                const float4 a = record_quad(rt, f + k, 0), b = record_quad(rt, f + k, 1), c = record_quad(rt, f + k, 2);
+#else
                 const float4* tp = S.prim + (size_t)(f + k) * kTriStride;
                 const float4 a = tp[0], b = tp[1], c = tp[2];
+#endif
                 hit = tri_hit(V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, V3{b.z, b.w, c.x}, o, d, &t, &u, &v, &det);
             }
             const unsigned long long m = __ballot(hit);
