@@ -58,11 +58,29 @@ PT_DEV uint32_t mulhi32(uint32_t a, uint32_t b) {
     return (uint32_t)(((uint64_t)a * b) >> 32);
 #endif
 }
+// Both halves of a 32x32 product.  PT_PHILOX_WIDE=1 takes them from one v_mad_u64_u32 (same issue cost as v_mul_hi_u32 alone,
+// tools/intrate.hip) where the compiler emits v_mul_hi_u32 + v_mul_lo_u32.  Measured 0.5-1 % SLOWER on C3/C4/C5
+// (profiles/r3_ab_philox_wide.txt: the kernel waits on memory, not on the multiplier, and the 64-bit results cost registers), so off.
+#ifndef PT_PHILOX_WIDE
+#define PT_PHILOX_WIDE 0
+#endif
+PT_DEV void mulwide32(uint32_t a, uint32_t b, uint32_t& hi, uint32_t& lo) {
+#if defined(__HIP_DEVICE_COMPILE__) && PT_PHILOX_WIDE
+    unsigned long long w;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(w) : "v"(a), "v"(b) : "vcc");
+    hi = (uint32_t)(w >> 32);
+    lo = (uint32_t)w;
+#else
+    hi = mulhi32(a, b);
+    lo = a * b;
+#endif
+}
 PT_DEV U4 philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        uint32_t h0 = mulhi32(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        uint32_t h1 = mulhi32(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        uint32_t h0, l0, h1, l1;
+        mulwide32(0xD2511F53u, c0, h0, l0);
+        mulwide32(0xCD9E8D57u, c2, h1, l1);
         c0 = h1 ^ c1 ^ k0;
         c1 = l1;
         c2 = h0 ^ c3 ^ k1;
