@@ -2,7 +2,7 @@
   profiles/r2_<tag>_{bench.json,kernel_stats.csv,pmc_k_path.json}   per profiled workload (tools/profile_r2.sh)
   profiles/r2_calib.json                                           calibration of FETCH_SIZE and of the VALU issue peak (tools/calib_r2.sh)
   profiles/r2_pmc.json                                             what bench.py reads: per-launch counters of k_path keyed workload:mode:spp:depth
-  profiles/<round>_pmc_table.md                                     the same numbers as the table DESIGN.md / profiles/README.md quote (generated, never typed)
+  profiles/<round>_pmc_table.md                                     the same numbers as the table DESIGN.md / BASELINE.md / profiles/README.md quote (generated, never typed)
 usage: ROUND=r3 python3 tools/make_pmc_json.py tag=WORKLOAD:SPP ..."""
 import json
 import os
@@ -88,7 +88,7 @@ def write_table(table):
             f"and one --pmc pass per counter group of the same command).  Rates use the live kernel time of that run's bench line.\n\n")
     open(os.path.join(DST, f"{RND}_pmc_table.md"), "w").write(head + "\n".join(rows) + "\n")
     # the same table between the markers of the documents that quote it
-    for doc in (os.path.join(DST, "README.md"), os.path.join(ROOT, "DESIGN.md")):
+    for doc in (os.path.join(DST, "README.md"), os.path.join(ROOT, "DESIGN.md"), os.path.join(ROOT, "BASELINE.md")):
         text = open(doc).read()
         a, b = text.find("<!-- pmc-table:begin -->"), text.find("<!-- pmc-table:end -->")
         if a >= 0 and b > a:
