@@ -464,10 +464,20 @@ def main():
                     roof["fabric_gather"] = {"achieved": req, "peak": peak_ic, "unit": "G 64-B read requests/s", "frac": req / peak_ic,
                                              "peak_hbm_resident": cal["fabric_gather_peak_g_requests_per_s_hbm"], "frac_of_hbm_resident_peak": req / cal["fabric_gather_peak_g_requests_per_s_hbm"],
                                              "l2_hit_rate": pmc["l2_hit_rate"],
-                                             "note": "L2-miss read requests (TCC_EA0_RDREQ) per second against the rate a pure random 64-B-record gather reaches on "
-                                                     "this GPU (tools/calib.hip, profiles/r3_calib.json: table resident in the Infinity Cache (frac) / a 1-GiB table in HBM (frac_of_hbm_resident_peak: the one "
-                                                     "that applies to C5, whose working set does not fit the cache); tables of 4 GiB and more gather at 19 G/s only). "
+                                             "note": "L2-miss read requests (TCC_EA0_RDREQ) per second against the rate a pure random gather of 64-B records reaches on "
+                                                     "this GPU when every wave follows a dependent chain with 4 loads in flight (tools/coop.hip, profiles/r3_calib.json: 64-MiB table resident in the "
+                                                     "Infinity Cache (frac) / 1-GiB table in HBM (frac_of_hbm_resident_peak: the one that applies to C5, whose working set does not fit the cache)). "
                                                      "A MEASURED peak, not a spec figure, so it is reported beside the headline, not as it"}
+                    vpk = cal.get("vmem_peak_g_wave_loads_per_s_l1_resident_full_waves")
+                    if vpk and "vmem_rd_insts_per_launch" in pmc:
+                        vm = pmc["vmem_rd_insts_per_launch"] / (ms_per_launch * 1e-3) / 1e9
+                        roof["vector_memory_pipe"] = {"achieved": vm, "peak": vpk, "unit": "G wave-level load instructions/s", "frac": vm / vpk,
+                                                      "peak_with_16_lanes_active": cal.get("vmem_peak_g_wave_loads_per_s_l1_resident_16_lanes"),
+                                                      "peak_from_l2_full_waves": cal.get("vmem_peak_g_wave_loads_per_s_l2_resident_full_waves"),
+                                                      "note": "SQ_INSTS_VMEM_RD per second against the rate at which the 256 CUs take buffer_load_dwordx4 instructions of full waves whose lines "
+                                                              "are all L1 hits (tools/coop.hip: 20.5 cycles per instruction and CU; 16 cycles is the floor, whatever the width of the load and "
+                                                              "however few lanes are active; every lane that misses L1 adds 0.36 cycles).  The busiest unit of the chip under k_path, and the "
+                                                              "reason an extra load per step costs 6 - 19 %.  MEASURED peak, beside the headline"}
                 roof["traffic"] = pmc["hbm_bytes_per_launch"]
                 roof["pmc_source"] = pmc.get("source", "profiles/r3_pmc.json")
                 top = "valu" if valu_frac >= hbm_frac else "hbm"

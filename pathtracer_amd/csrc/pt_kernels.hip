@@ -53,6 +53,16 @@ __device__ __forceinline__ float4 record_quad(__amdgpu_buffer_rsrc_t r, uint32_t
     const f4v v = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(r, (int)(index << 6) + 16 * quad, 0, 0));
     return make_float4(v.x, v.y, v.z, v.w);
 }
+// PT_TOUCH_NEXT: at the end of a traversal turn of k_path a lane knows the record it will read at its next turn (T.cur).  A one-dword
+// buffer load of that record WITH LDS AS ITS DESTINATION (no VGPR, nothing waits for it) starts the fetch a scheduling round early.
+// Not speculative: it is the record the lane reads next, whatever happens.  1 = node records, 2 = also the first triangle of a leaf.
+#ifndef PT_TOUCH_NEXT
+#define PT_TOUCH_NEXT 0
+#endif
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ void record_touch(__amdgpu_buffer_rsrc_t r, uint32_t index, lds_u32* wave_dump) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, wave_dump, 4, (int)(index << 6), 0, 0, 0);
+}
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -1411,6 +1421,10 @@ __global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, c
                                                       float4* __restrict__ out, uint32_t* __restrict__ cursor, RedoList redo, LaunchCfg cfg,
                                                       unsigned long long* counters) {
     __shared__ unsigned long long smem[kLdsStack * kTraceBlock];
+#if PT_TOUCH_NEXT
+    __shared__ uint32_t touch_dump[kTraceBlock];  // where the touches land: a dword per lane, never read
+    lds_u32* const wave_dump = (lds_u32*)touch_dump + (threadIdx.x & ~63u);
+#endif
     LaneStack stk = make_stack(smem, cfg);
     const DevCamera cam = *camp;
     const uint32_t n = n_samples * M.npix_pad;
@@ -1575,6 +1589,13 @@ __global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, c
                 pending = true;
                 if (COUNT) worst = mine > worst ? mine : worst;
             }
+#if PT_TOUCH_NEXT
+            if (active && !(T.cur & kLeafBit)) record_touch(record_rsrc(S.pairs, S.n_pairs + 1u), T.cur, wave_dump);
+#if PT_TOUCH_NEXT >= 2
+            if (PRIM == PRIM_TRIANGLE && active && (T.cur & kLeafBit) && ((T.cur >> kLeafCountShift) & 31u) != 0u)
+                record_touch(record_rsrc(S.prim, S.n_prims), T.cur & kLeafFirstMask, wave_dump);
+#endif
+#endif
         }
     }
 #ifdef PT_PHASE_STATS

@@ -26,5 +26,7 @@ timeout -s KILL 120 rocprofv3 --pmc GRBM_GUI_ACTIVE -d $O/p_valu_clk -o p --outp
 for k in stream gather_hbm gather_mall gather_req; do python3 tools/pmc_to_json.py "k_" $O/p_$k > $O/p_$k.json; done
 python3 tools/pmc_to_json.py "k_valu(" $O/p_valu $O/p_valu_clk > $O/p_valu.json
 python3 tools/pmc_to_json.py "k_valu_pk" $O/p_valu_pk $O/p_valu_pk_clk > $O/p_valu_pk.json
+# the vector-memory pipe of a CU and the gather rate of dependent chains (tools/coop.hip): tables in L1, L2, the Infinity Cache, HBM
+if [ -x $R/tools/coop ]; then for k in 16 2048 65536 1048576 2097152; do timeout -k 10 120 $R/tools/coop $k 1000 || exit 1; done > $O/coop.txt 2>&1; fi
 cat $O/*.txt
 echo "calib done"

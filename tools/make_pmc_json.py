@@ -60,6 +60,24 @@ def calib():
         "valu_issue_plain": valu_entry(valu, p_valu, p_clk, "independent v_mul_f32 / v_add_f32 (inline asm), 6144 waves = 6 per SIMD"),
         "valu_issue_packed": valu_entry(valu_pk, p_valu_pk, p_pk_clk, "the same with v_pk_mul_f32 / v_pk_add_f32 (two fp32 operations per lane per instruction)"),
     }
+    if os.path.exists(os.path.join(c, "coop.txt")):
+        # tools/coop.hip: every wave a dependent chain of random 64-B records, 4 loads in flight, 6 waves per SIMD
+        rows = lines("coop.txt")
+        by = {}
+        for r in rows:
+            e = by.setdefault(f"{r['table_kib']}KiB", {}).setdefault(r["mode"], {"g_wave_loads_per_s": 0.0})
+            e["g_wave_loads_per_s"] = max(e["g_wave_loads_per_s"], r["g_wave_loads_per_s"])
+        for t in by.values():
+            for m, e in t.items():
+                e["cu_cycles_per_wave_load_at_2.3GHz"] = 256 * 2.3 / e["g_wave_loads_per_s"]
+                if m == "lane":
+                    e["g_records_per_s"] = e["g_wave_loads_per_s"] * 16  # 4 wave-loads fetch 64 records
+        out["vector_memory_pipe"] = {
+            "how": "tools/coop.hip: modes lane = 4 x buffer_load_dwordx4 per lane and round (k_path's node fetch), lane_16_first / lane_16_spread = the same with 16 of 64 lanes "
+                   "active, lane_dwordxN = loads of N dwords, quad = the 4 lanes of a quad share 4 records (16 segments per instruction)",
+            "by_table_size": by,
+            "finding": "a vector load costs the CU's memory pipe 16 - 21 cycles whatever its width (dword 18, dwordx4 20.5) and however few lanes are active (16 of 64: 15.6 - 17)",
+        }
     json.dump(out, open(os.path.join(DST, f"{RND}_calib.json"), "w"), indent=1)
     return out
 
@@ -67,8 +85,8 @@ def calib():
 def write_table(table):
     """profiles/<round>_pmc_table.md: per workload, what the counters and the bench line of the same profiling run say."""
     cal = table.get("_calibration", {})
-    rows = ["| workload | Grays/s | k_path ms per launch | node tests / ray | prim tests / ray | algorithmic GB per launch (over HBM peak) | fabric GB per launch | HBM frac | L2 hit | L2-miss requests G/s (of the gather rate) | VALU G wave-inst/s (frac) | lanes active | lane frac | waves waiting |",
-            "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
+    rows = ["| workload | Grays/s | k_path ms per launch | node tests / ray | prim tests / ray | algorithmic GB per launch (over HBM peak) | fabric GB per launch | HBM frac | L2 hit | L2-miss requests G/s (of the gather rate) | vector loads G wave-inst/s (of the L1-resident rate) | VALU G wave-inst/s (frac) | lanes active | lane frac | waves waiting |",
+            "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
     for key in sorted(k for k in table if not k.startswith("_")):
         p = table[key]
         wl, _, spp, _ = key.split(":")
@@ -80,9 +98,10 @@ def write_table(table):
         req = p["ea_read_requests_per_launch"] / ms / 1e6
         peak = cal.get("fabric_gather_peak_g_requests_per_s_hbm" if wl == "C5" else "fabric_gather_peak_g_requests_per_s_infinity_cache", float("nan"))
         valu = p["valu_wave_insts_per_launch"] / ms / 1e6
+        vmem, vmem_peak = p["vmem_rd_insts_per_launch"] / ms / 1e6, cal.get("vmem_peak_g_wave_loads_per_s_l1_resident_full_waves", float("nan"))
         rows.append(f"| {wl} ({spp} spp / launch) | {b['value'] / 1e3:.2f} | {ms:.1f} | {r['algorithmic']['node_tests_per_ray']:.1f} | {r['algorithmic']['prim_tests_per_ray']:.2f} | "
                     f"{r['algorithmic']['bytes_per_launch'] / 1e9:.0f} ({r['algorithmic']['over_hbm_peak']:.2f}) | {p['hbm_bytes_per_launch'] / 1e9:.1f} | {hbm / 8000:.2f} | "
-                    f"{p['l2_hit_rate']:.2f} | {req:.1f} ({req / peak:.2f} of {'HBM-resident (1-GiB table)' if wl == 'C5' else 'Infinity-Cache-resident'} {peak:.1f}) | {valu:.0f} ({valu / 1228.8:.2f}) | "
+                    f"{p['l2_hit_rate']:.2f} | {req:.1f} ({req / peak:.2f} of {'HBM-resident (1-GiB table)' if wl == 'C5' else 'Infinity-Cache-resident'} {peak:.1f}) | {vmem:.1f} ({vmem / vmem_peak:.2f} of {vmem_peak:.1f}) | {valu:.0f} ({valu / 1228.8:.2f}) | "
                     f"{p['lane_util']:.2f} | {valu / 1228.8 * p['lane_util']:.2f} | {p['wave_wait_any_frac']:.2f} |")
     head = (f"Generated by tools/make_pmc_json.py from profiles/{RND}_pmc.json and profiles/{RND}_<tag>_bench.json (one profiling run per workload: bench line, rocprofv3 kernel stats "
             f"and one --pmc pass per counter group of the same command).  Rates use the live kernel time of that run's bench line.\n\n")
@@ -128,15 +147,25 @@ def main():
             "clock_ghz_under_pmc": grbm["GRBM_GUI_ACTIVE"] / 8 / (grbm["dur_ms"] * 1e6),
         }
     if cal:
-        table["_calibration"] = {"fabric_gather_peak_g_requests_per_s_infinity_cache": cal["gather_64B_records_infinity_cache_128MiB"]["g_requests_per_s"],
-                                 # HBM-resident working sets here are 1 - 2 GiB (C5: 1.4 GB): the rate of a 1-GiB table, not of the 4-GiB one behind
-                                 # the cliff (19 G/s) that round 2 used
-                                 "fabric_gather_peak_g_requests_per_s_hbm": cal["gather_64B_records_by_table_size"].get("1024MiB", cal["gather_64B_records_hbm_4GiB"])["g_requests_per_s"],
-                                 "fabric_gather_peak_g_requests_per_s_hbm_tables_of_4GiB_and_more": cal["gather_64B_records_hbm_4GiB"]["g_requests_per_s"],
-                                 "valu_plain_measured_g_wave_insts_per_s": cal["valu_issue_plain"]["g_wave_insts_per_s_best"],
-                                 "valu_plain_simd_cycles_per_wave_inst": cal["valu_issue_plain"]["simd_cycles_per_wave_inst_under_pmc"],
-                                 "valu_packed_simd_cycles_per_wave_inst": cal["valu_issue_packed"]["simd_cycles_per_wave_inst_under_pmc"],
-                                 "source": f"profiles/{RND}_calib.json"}
+        ic = cal["gather_64B_records_infinity_cache_128MiB"]["g_requests_per_s"]
+        # HBM-resident working sets here are 1 - 2 GiB (C5: 1.4 GB): the rate of a 1-GiB table, not of the 4-GiB one behind the cliff (19 G/s) that round 2 used
+        hbm = cal["gather_64B_records_by_table_size"].get("1024MiB", cal["gather_64B_records_hbm_4GiB"])["g_requests_per_s"]
+        c = {"fabric_gather_read_once_g_requests_per_s_infinity_cache": ic, "fabric_gather_read_once_g_requests_per_s_hbm": hbm,
+             "fabric_gather_peak_g_requests_per_s_hbm_tables_of_4GiB_and_more": cal["gather_64B_records_hbm_4GiB"]["g_requests_per_s"]}
+        vm = cal.get("vector_memory_pipe", {}).get("by_table_size")
+        if vm:
+            # dependent chains with 4 loads in flight per wave (tools/coop.hip) gather 2 - 3 times faster than the read-once kernel of tools/calib.hip: the higher rate is the roof
+            ic, hbm = max(ic, vm["65536KiB"]["lane"]["g_records_per_s"]), max(hbm, vm["1048576KiB"]["lane"]["g_records_per_s"])
+            c["vmem_peak_g_wave_loads_per_s_l1_resident_full_waves"] = vm["16KiB"]["lane"]["g_wave_loads_per_s"]
+            c["vmem_peak_g_wave_loads_per_s_l1_resident_16_lanes"] = vm["16KiB"]["lane_16_spread"]["g_wave_loads_per_s"]
+            c["vmem_peak_g_wave_loads_per_s_l2_resident_full_waves"] = vm["2048KiB"]["lane"]["g_wave_loads_per_s"]
+            c["vmem_peak_g_wave_loads_per_s_l2_resident_16_lanes"] = vm["2048KiB"]["lane_16_spread"]["g_wave_loads_per_s"]
+        c.update({"fabric_gather_peak_g_requests_per_s_infinity_cache": ic, "fabric_gather_peak_g_requests_per_s_hbm": hbm,
+                  "valu_plain_measured_g_wave_insts_per_s": cal["valu_issue_plain"]["g_wave_insts_per_s_best"],
+                  "valu_plain_simd_cycles_per_wave_inst": cal["valu_issue_plain"]["simd_cycles_per_wave_inst_under_pmc"],
+                  "valu_packed_simd_cycles_per_wave_inst": cal["valu_issue_packed"]["simd_cycles_per_wave_inst_under_pmc"],
+                  "source": f"profiles/{RND}_calib.json"})
+        table["_calibration"] = c
     json.dump(table, open(path, "w"), indent=1, sort_keys=True)
     write_table(table)
     print(json.dumps(table, indent=1)[:3000])
