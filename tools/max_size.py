@@ -105,7 +105,14 @@ if with_oracle:
     gh = g.trace(sub)
     same_h = np.asarray(oh).tobytes() == np.asarray(gh).tobytes()
     say("100 k rays, GPU hits == oracle hits:", same_h)
-    ok = ok and same_o and same_h
+    # the frame above through the oracle: k_path's own node and primitive fetches at the size limit (the last records of both arrays included)
+    o.set_camera((0.0, 1.0, 3.5), (0.0, 0.6, 0.0), 256, 256)
+    t0 = time.time()
+    o.render(4, 8, seed=1)
+    oacc, ospp = o.read_accum()
+    same_f = ospp == spp and np.asarray(oacc).tobytes() == np.asarray(acc).tobytes()
+    say(f"256 x 256 frame through the oracle in {time.time() - t0:.1f} s, GPU sums == oracle sums: {same_f}")
+    ok = ok and same_o and same_h and same_f
 alive = False
 say("OK" if ok else "MISMATCH")
 sys.exit(0 if ok else 1)
