@@ -279,8 +279,11 @@ int pt_create(int device, pt_ctx** out) {
             return PT_ERR_HIP;
         }
     }
+    // (a memset of device memory on the null stream may still be running when the call returns, and the library's non-blocking
+    // streams do not wait for the null stream: clear on the context's stream and wait for it)
     if (dev_alloc(c, c->d_counters, CNT_N * sizeof(unsigned long long)) != PT_OK ||
-        hipMemset(c->d_counters.p, 0, CNT_N * sizeof(unsigned long long)) != hipSuccess) {
+        hipMemsetAsync(c->d_counters.p, 0, CNT_N * sizeof(unsigned long long), c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) {
         pt_destroy(c);
         return PT_ERR_HIP;
     }
@@ -1602,7 +1605,8 @@ int pt_reset_counters(pt_ctx* c) {
     if (!c) return PT_ERR_INVALID;
     if (int rc = drain(c)) return rc;
     PT_HIP(c, hipSetDevice(c->device));
-    PT_HIP(c, hipMemset(c->d_counters.p, 0, CNT_N * sizeof(unsigned long long)));
+    PT_HIP(c, hipMemsetAsync(c->d_counters.p, 0, CNT_N * sizeof(unsigned long long), c->stream));
+    PT_HIP(c, hipStreamSynchronize(c->stream));  // the launches that count run on other streams
     c->extend_launches = 0;
     c->tail_launches = 0;
     c->render_ms = 0;
