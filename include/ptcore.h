@@ -269,6 +269,9 @@ int pt_sample_skybox(pt_ctx *ctx, const float *dirs, uint64_t n, float *rgb);
  *                         larger launches when calls arrive faster than they are rendered
  *  PT_OPT_REDO_CAPACITY  paths per batch that may ask for the literal NEE block before the whole batch is run again with the
  *                         NEE kernels (default 65536; tests set it to 0 to exercise the restart)
+ *  PT_OPT_WAVES_PER_SIMD  which form of the path kernel runs: 6 = six waves per SIMD (80 registers, 12 stack levels in LDS), 7 = seven
+ *                         (72 registers, 11 levels), 0 (default) = seven when node and primitive records exceed the 256-MB Infinity Cache
+ *                         (their fetches then wait longest), else six.  Same results either way
  * and ONE knob that changes what is executed, though not a single sum (default 0; bench.py's metric run never sets it):
  *  PT_OPT_SKIP_REPEATED_MISS  1 = when the look-ahead trace of a diffuse bounce (src/camera.rs:362) missed everything, the
  *                         reference's re-trace of that very ray in the next iteration (quirk Q3: the hit is dropped, ray.distance
@@ -276,7 +279,7 @@ int pt_sample_skybox(pt_ctx *ctx, const float *dirs, uint64_t n, float *rgb);
  *                         for bit, fewer intersect_closest traversals: rays_closest then counts what was executed, which is no
  *                         longer the reference's number of traversals */
 enum { PT_OPT_BATCH_PATHS = 0, PT_OPT_LANES = 1, PT_OPT_TAIL_MIN_PATHS = 2, PT_OPT_TAIL_FRACTION = 3,
-       PT_OPT_TAIL_STREAMS = 4, PT_OPT_TAIL_PATHS_PER_LANE = 5, PT_OPT_SIMPLE_EXTEND = 6, PT_OPT_BULK_STREAMS = 7, PT_OPT_TAIL_MODE = 8, PT_OPT_FIRST_CHECK_ROUND = 9, PT_OPT_RENDER_MODE = 10, PT_OPT_MERGE_QUEUED_CALLS = 11, PT_OPT_DEVICE_BUILD = 12, PT_OPT_REDO_CAPACITY = 13, PT_OPT_SKIP_REPEATED_MISS = 14 };
+       PT_OPT_TAIL_STREAMS = 4, PT_OPT_TAIL_PATHS_PER_LANE = 5, PT_OPT_SIMPLE_EXTEND = 6, PT_OPT_BULK_STREAMS = 7, PT_OPT_TAIL_MODE = 8, PT_OPT_FIRST_CHECK_ROUND = 9, PT_OPT_RENDER_MODE = 10, PT_OPT_MERGE_QUEUED_CALLS = 11, PT_OPT_DEVICE_BUILD = 12, PT_OPT_REDO_CAPACITY = 13, PT_OPT_SKIP_REPEATED_MISS = 14, PT_OPT_WAVES_PER_SIMD = 15 };
 int pt_set_option(pt_ctx *ctx, int option, uint64_t value);
 int pt_get_counters(pt_ctx *ctx, pt_counters *out);
 /* Diagnostics of the wavefront loop (no counterpart in the reference): after a pt_render with

@@ -73,6 +73,7 @@ struct RenderLane {
                                // more paths asked for the block than the redo list holds)
     PathState ps{};
     LaunchCfg cfg{};
+    LaunchCfg cfg7{};   // for k_path's 7-wave form: larger grid, same spill area
     uint64_t cap_slots = 0;
     uint32_t qn_len = 0;
     uint32_t batch = 0, ns = 0, sample_base = 0, round = 0, live = 0;
@@ -167,6 +168,9 @@ struct pt_ctx {
 
     // pipeline
     LaunchCfg cfg{};          // grid geometry; every lane has its own spill area
+    LaunchCfg cfg7{};         // for k_path's 7-wave form (pt_kernels.h, kLdsStack7)
+    uint64_t opt_waves = 0;   // PT_OPT_WAVES_PER_SIMD: 0 = by scene size, 6, 7
+    bool auto_seven = false;  // the scene's records do not fit the Infinity Cache (decided at pt_build)
     size_t spill_bytes = 16;
     DevBuf d_spill;           // spill area of the seams (pt_trace, focus)
     unsigned char* scratch_ptr = nullptr;  // this device's copy of the static scratch array (pt_trace_noalloc)
@@ -293,6 +297,10 @@ int pt_create(int device, pt_ctx** out) {
     c->cfg.grid = std::max<uint32_t>(1, (uint32_t)c->num_cu * waves_per_cu / (kTraceBlock / 64));
     c->cfg.spill = nullptr;
     c->cfg.spill_stride = c->cfg.grid * kTraceBlock;
+    const uint32_t waves7 = std::min<uint32_t>(kWavesPerCU7, (160u * 1024u) / (kLdsStack7 * 64 * 8));
+    c->cfg7.grid = std::max<uint32_t>(1, (uint32_t)c->num_cu * waves7 / (kTraceBlock / 64));
+    c->cfg7.spill = nullptr;
+    c->cfg7.spill_stride = c->cfg7.grid * kTraceBlock;
     *out = c;
     return PT_OK;
 }
@@ -674,10 +682,15 @@ static int finalize_scene(pt_ctx* c) {
     S.nee_literal = literal && S.n_lights != 0 ? 1u : 0u;
     if (S.nee_literal) c->nee = true;  // such a scene runs the kernels with the NEE code throughout
     // overflow area of the LDS stacks: exactly the levels the tree can need beyond kLdsStack
+    // (sized for both forms of k_path: the 7-wave one keeps one level less in LDS and has more lanes in flight)
     const uint32_t extra = S.stack_cap > (uint32_t)kLdsStack ? S.stack_cap - kLdsStack : 0;
-    c->spill_bytes = (size_t)std::max(extra, 1u) * c->cfg.spill_stride * sizeof(unsigned long long);
+    const uint32_t extra7 = S.stack_cap > (uint32_t)kLdsStack7 ? S.stack_cap - kLdsStack7 : 0;
+    c->spill_bytes = std::max((size_t)std::max(extra, 1u) * c->cfg.spill_stride, (size_t)std::max(extra7, 1u) * c->cfg7.spill_stride) * sizeof(unsigned long long);
     if ((rc = dev_alloc(c, c->d_spill, c->spill_bytes))) return rc;
     c->cfg.spill = (unsigned long long*)c->d_spill.p;
+    // Node and primitive records beyond what the 256-MB Infinity Cache holds come from HBM, a step then waits longest, and a
+    // seventh wave per SIMD hides more than its 8 registers cost (C5 +3.4 %; C3 / C4, whose records fit, -1.4 % / -2.0 %)
+    c->auto_seven = c->d_pairs.bytes + c->d_prim.bytes > (size_t)256 << 20;
     c->built = true;
     c->have_cam = false;
     return PT_OK;
@@ -900,6 +913,8 @@ static int lane_alloc(pt_ctx* c, RenderLane& L, uint64_t slots, uint32_t rounds)
     L.ps.pxs = (uint2*)L.d_pxs.p;
     L.cfg = c->cfg;
     L.cfg.spill = (unsigned long long*)L.d_spill.p;
+    L.cfg7 = c->cfg7;
+    L.cfg7.spill = L.cfg.spill;
     return PT_OK;
 }
 
@@ -959,8 +974,9 @@ static int lane_start(pt_ctx* c, RenderLane& L, RenderJob& J, uint32_t batch, ui
     if (c->opt_render_mode == 1) {
         // the whole batch in one persistent kernel (generate + sample, state in registers)
         if ((rc = timed_begin(c, J, J.tail_events, L.stream))) return rc;
+        const bool seven = c->opt_waves == 7 || (c->opt_waves == 0 && c->auto_seven);
         launch_path(c->prim_kind, L.nee, J.count, c->ds, (const DevCamera*)c->d_cam.p, J.M, ns, sample_base, J.max_depth, J.k0, J.k1,
-                    L.ps.out, qn + 2 * (J.rounds + 2), L.ps.redo, L.cfg, (unsigned long long*)c->d_counters.p, L.stream);
+                    L.ps.out, qn + 2 * (J.rounds + 2), L.ps.redo, seven ? L.cfg7 : L.cfg, seven, (unsigned long long*)c->d_counters.p, L.stream);
         if ((rc = timed_end(c, J, J.tail_events, L.stream))) return rc;
         c->tail_launches += 1;
         PT_HIP(c, hipMemcpyAsync(L.h_qn + 1, L.ps.redo.count, 4, hipMemcpyDeviceToHost, L.stream));
@@ -1541,6 +1557,10 @@ int pt_set_option(pt_ctx* c, int option, uint64_t value) {
         case PT_OPT_TAIL_PATHS_PER_LANE: c->opt_tail_paths_per_lane = std::max<uint64_t>(value, 1); return PT_OK;
         case PT_OPT_REDO_CAPACITY: c->opt_redo_cap = std::min<uint64_t>(value, 1u << 28); return PT_OK;
         case PT_OPT_SKIP_REPEATED_MISS: c->ds.skip_repeated_miss = value ? 1u : 0u; return PT_OK;
+        case PT_OPT_WAVES_PER_SIMD:
+            if (value != 0 && value != 6 && value != 7) return c->fail(PT_ERR_INVALID, "pt_set_option: PT_OPT_WAVES_PER_SIMD takes 0 (by scene size), 6 or 7");
+            c->opt_waves = value;
+            return PT_OK;
         default: return c->fail(PT_ERR_INVALID, "pt_set_option: unknown option");
     }
 }

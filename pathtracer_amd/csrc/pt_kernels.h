@@ -100,6 +100,11 @@ constexpr int kNrmStride = PT_NRM_STRIDE;     // floats per slot of the normals 
 constexpr int kTraceBlock = PT_TRACE_BLOCK;  // threads per traversal workgroup
 constexpr int kLdsStack = PT_LDS_STACK;      // stack entries per lane kept in LDS
 constexpr int kWavesPerCU = PT_WAVES_PER_CU; // persistent grid: waves launched per CU (what fits is decided by LDS and VGPRs)
+// k_path's second form for scenes whose records come from HBM (their steps wait longest, so one more wave per SIMD pays more than
+// the 8 registers it takes away: C5 +3.4 %, profiles/r3_ab_waves_per_simd_final_kernels.txt): 7 waves per SIMD at 72 VGPRs, and one LDS
+// stack level less so that 28 waves fit a CU's 160 KB
+constexpr int kLdsStack7 = PT_LDS_STACK - 1;
+constexpr int kWavesPerCU7 = 28;
 
 // parity seams
 void launch_trace(int prim, bool any_hit, bool count, const DevScene& S, const pt_ray* rays, uint64_t n, pt_hit* hits,
@@ -122,7 +127,7 @@ void launch_tail(int prim, bool nee, bool count, int mode, const DevScene& S, co
                  hipStream_t st);
 void launch_path(int prim, bool nee, bool count, const DevScene& S, const DevCamera* cam, const PixelMap& M, uint32_t n_samples,
                  uint32_t sample_base, uint32_t depth, uint32_t k0, uint32_t k1, float4* out, uint32_t* cursor, const RedoList& redo,
-                 const LaunchCfg& cfg, unsigned long long* counters, hipStream_t st);
+                 const LaunchCfg& cfg, bool seven_waves, unsigned long long* counters, hipStream_t st);
 // the paths on a redo list, start to end, with the NEE code (one lane per path); pixel_major = the slot layout of k_path
 void launch_redo(int prim, bool count, const DevScene& S, const DevCamera* cam, const PixelMap& M, uint32_t n_samples, bool pixel_major,
                  uint32_t sample_base, uint32_t depth, uint32_t k0, uint32_t k1, float4* out, const uint32_t* list, uint32_t n,

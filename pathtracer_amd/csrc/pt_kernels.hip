@@ -29,7 +29,7 @@
 // k_path: 6 waves per SIMD (80 VGPRs, the shading temporaries spill) measured faster than 4 waves
 // without spills: the kernel lives on latency hiding.
 #ifndef PT_PATH_ATTR
-#define PT_PATH_ATTR __attribute__((amdgpu_waves_per_eu(6, 6)))
+#define PT_PATH_ATTR __attribute__((amdgpu_waves_per_eu(SEVEN ? 7 : 6, SEVEN ? 7 : 6)))  // SEVEN: k_path's template argument (pt_kernels.h, kLdsStack7)
 #endif
 
 namespace pt {
@@ -75,17 +75,18 @@ struct LaneStack {
     lds_u64* lds;         // &smem[threadIdx.x], kept in the LDS address space so accesses are ds_read/ds_write_b64
     unsigned long long* spill;  // the launch's spill area (wave-uniform; a lane's entries are at [level][global thread id])
     uint32_t spill_stride;
+    uint32_t levels;      // levels kept in LDS (a constant at every call site of make_stack: kLdsStack, or kLdsStack7 in k_path's 7-wave form)
     __device__ __forceinline__ unsigned long long* spill_at(uint32_t level) const {
-        return spill + ((size_t)(level - kLdsStack) * spill_stride + (blockIdx.x * blockDim.x + threadIdx.x));
+        return spill + ((size_t)(level - levels) * spill_stride + (blockIdx.x * blockDim.x + threadIdx.x));
     }
     __device__ __forceinline__ void put(uint32_t level, uint32_t ref, float tmin) const {
         const unsigned long long e = (unsigned long long)ref | ((unsigned long long)__float_as_uint(tmin) << 32);
-        if (level < (uint32_t)kLdsStack) lds[level * kTraceBlock] = e;
+        if (level < levels) lds[level * kTraceBlock] = e;
         else *spill_at(level) = e;
     }
     __device__ __forceinline__ void get(uint32_t level, uint32_t* ref, float* tmin) const {
         unsigned long long e;
-        if (level < (uint32_t)kLdsStack) e = lds[level * kTraceBlock];
+        if (level < levels) e = lds[level * kTraceBlock];
         else e = *spill_at(level);
         *ref = (uint32_t)e;
         *tmin = __uint_as_float((uint32_t)(e >> 32));
@@ -200,11 +201,12 @@ __device__ __forceinline__ void traverse(const DevScene& S, V3 o, V3 d, float& d
     }
 }
 
-__device__ __forceinline__ LaneStack make_stack(unsigned long long* smem, const LaunchCfg& cfg) {
+__device__ __forceinline__ LaneStack make_stack(unsigned long long* smem, const LaunchCfg& cfg, uint32_t levels = (uint32_t)kLdsStack) {
     LaneStack s;
     s.lds = (lds_u64*)smem + threadIdx.x;
     s.spill = cfg.spill;
     s.spill_stride = cfg.spill_stride;
+    s.levels = levels;
     return s;
 }
 
@@ -1415,17 +1417,18 @@ __global__ __launch_bounds__(kTraceBlock) void k_tail_pw(DevScene S, PathState P
 //   * the only per-path HBM traffic is the 16-byte radiance written when the path ends.
 // slots are pixel-major (8x8-tile pixel order, then the samples of the pixel), and every value is
 // computed by the same device functions, so the sums are bit-identical.
-template <int PRIM, bool NEE, bool COUNT>
+template <int PRIM, bool NEE, bool COUNT, bool SEVEN>
 __global__ __launch_bounds__(kTraceBlock) PT_PATH_ATTR void k_path(DevScene S, const DevCamera* __restrict__ camp, PixelMap M, uint32_t n_samples, FastDiv fd_samples,
                                                       uint32_t sample_base, uint32_t depth, uint32_t k0, uint32_t k1,
                                                       float4* __restrict__ out, uint32_t* __restrict__ cursor, RedoList redo, LaunchCfg cfg,
                                                       unsigned long long* counters) {
-    __shared__ unsigned long long smem[kLdsStack * kTraceBlock];
+    constexpr int kLevels = SEVEN ? kLdsStack7 : kLdsStack;
+    __shared__ unsigned long long smem[kLevels * kTraceBlock];
 #if PT_TOUCH_NEXT
     __shared__ uint32_t touch_dump[kTraceBlock];  // where the touches land: a dword per lane, never read
     lds_u32* const wave_dump = (lds_u32*)touch_dump + (threadIdx.x & ~63u);
 #endif
-    LaneStack stk = make_stack(smem, cfg);
+    LaneStack stk = make_stack(smem, cfg, (uint32_t)kLevels);
     const DevCamera cam = *camp;
     const uint32_t n = n_samples * M.npix_pad;
     const uint32_t lane = threadIdx.x & 63u;
@@ -1850,10 +1853,11 @@ void launch_tail(int prim, bool nee, bool count, int mode, const DevScene& S, co
 
 void launch_path(int prim, bool nee, bool count, const DevScene& S, const DevCamera* cam, const PixelMap& M, uint32_t n_samples,
                  uint32_t sample_base, uint32_t depth, uint32_t k0, uint32_t k1, float4* out, uint32_t* cursor, const RedoList& redo,
-                 const LaunchCfg& cfg, unsigned long long* counters, hipStream_t st) {
+                 const LaunchCfg& cfg, bool seven_waves, unsigned long long* counters, hipStream_t st) {
     const uint64_t total = (uint64_t)n_samples * M.npix_pad;
     const uint32_t grid = blocks_for(total, kTraceBlock, cfg.grid);
-#define PT_PATH(PR, N, C) hipLaunchKernelGGL((k_path<PR, N, C>), dim3(grid), dim3(kTraceBlock), 0, st, S, cam, M, n_samples, fastdiv_make(n_samples), sample_base, depth, k0, k1, out, cursor, redo, cfg, counters)
+#define PT_PATH4(PR, N, C, W) hipLaunchKernelGGL((k_path<PR, N, C, W>), dim3(grid), dim3(kTraceBlock), 0, st, S, cam, M, n_samples, fastdiv_make(n_samples), sample_base, depth, k0, k1, out, cursor, redo, cfg, counters)
+#define PT_PATH(PR, N, C) do { if (seven_waves) PT_PATH4(PR, N, C, true); else PT_PATH4(PR, N, C, false); } while (0)
     if (prim == PRIM_TRIANGLE) {
         if (nee) { if (count) PT_PATH(PRIM_TRIANGLE, true, true); else PT_PATH(PRIM_TRIANGLE, true, false); }
         else { if (count) PT_PATH(PRIM_TRIANGLE, false, true); else PT_PATH(PRIM_TRIANGLE, false, false); }
@@ -1862,6 +1866,7 @@ void launch_path(int prim, bool nee, bool count, const DevScene& S, const DevCam
         else { if (count) PT_PATH(PRIM_SPHERE, false, true); else PT_PATH(PRIM_SPHERE, false, false); }
     }
 #undef PT_PATH
+#undef PT_PATH4
 }
 
 void launch_redo(int prim, bool count, const DevScene& S, const DevCamera* cam, const PixelMap& M, uint32_t n_samples, bool pixel_major,

@@ -33,7 +33,7 @@ PT_OK = 0
 PT_ERR_INVALID, PT_ERR_STATE, PT_ERR_NO_DEVICE, PT_ERR_HIP, PT_ERR_LIMIT, PT_ERR_BVH = -1, -2, -3, -4, -5, -6
 SHARD_ALL, SHARD_TILES = 0, 1
 RENDER_TIMED, RENDER_COUNT = 1, 2
-OPT_BATCH_PATHS, OPT_LANES, OPT_TAIL_MIN_PATHS, OPT_TAIL_FRACTION, OPT_TAIL_STREAMS, OPT_TAIL_PATHS_PER_LANE, OPT_SIMPLE_EXTEND, OPT_BULK_STREAMS, OPT_TAIL_MODE, OPT_FIRST_CHECK_ROUND, OPT_RENDER_MODE, OPT_MERGE_QUEUED_CALLS, OPT_DEVICE_BUILD, OPT_REDO_CAPACITY, OPT_SKIP_REPEATED_MISS = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14
+OPT_BATCH_PATHS, OPT_LANES, OPT_TAIL_MIN_PATHS, OPT_TAIL_FRACTION, OPT_TAIL_STREAMS, OPT_TAIL_PATHS_PER_LANE, OPT_SIMPLE_EXTEND, OPT_BULK_STREAMS, OPT_TAIL_MODE, OPT_FIRST_CHECK_ROUND, OPT_RENDER_MODE, OPT_MERGE_QUEUED_CALLS, OPT_DEVICE_BUILD, OPT_REDO_CAPACITY, OPT_SKIP_REPEATED_MISS, OPT_WAVES_PER_SIMD = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15
 
 EXPORTS = [
     "pt_strerror", "pt_last_error", "pt_create", "pt_destroy", "pt_set_triangles", "pt_set_spheres", "pt_set_materials",

@@ -80,6 +80,7 @@ def main():
             name, scene = name + "+spoilt", spoil_colours(rng, scene)
         g = ptcore.PathTracer(0).set_scene(scene, sky)
         g.set_option(ptcore.OPT_REDO_CAPACITY, int(rng.choice([65536, 65536, 5, 0])))
+        g.set_option(ptcore.OPT_WAVES_PER_SIMD, int(rng.choice([0, 6, 7])))  # both forms of the path kernel (these scenes would all get the 6-wave one)
         device_builds += int(g.build_info()[0])
         o = orc.from_scene(scene, sky)
         what = "bvh"

@@ -284,8 +284,42 @@ def test_deep_tree_spills_past_lds_stack(ptcore, orc, sky):
     o.set_camera((-3.0, 0.5, -2.5), (0.0, 0.3, 0.0), 48, 32)
     g.render(1, 32, seed=4)
     o.render(1, 32, seed=4, nee_mode=0)
-    assert g.read_accum()[0].tobytes() == o.read_accum()[0].tobytes()
+    want = o.read_accum()[0].tobytes()
+    assert g.read_accum()[0].tobytes() == want
+    # both forms of the path kernel: 12 stack levels in LDS at six waves per SIMD, 11 at seven (one more level spills)
+    for waves in (6, 7):
+        g.set_option(ptcore.OPT_WAVES_PER_SIMD, waves)
+        g.reset_accum()
+        g.render(1, 32, seed=4)
+        assert g.read_accum()[0].tobytes() == want, waves
     g.close()
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_both_forms_of_the_path_kernel_give_the_reference_sums(pairs, ptcore, name):
+    """PT_OPT_WAVES_PER_SIMD: the 7-wave form of k_path (72 registers, 11 LDS stack levels; chosen by itself only for scenes whose
+    records exceed the Infinity Cache) against the 6-wave form and the oracle's literal loop, with the work counters."""
+    g, o, scene, cam_o, cam_t = pairs[name]
+    g.set_camera(cam_o, cam_t, 80, 56)
+    o.set_camera(cam_o, cam_t, 80, 56)
+    o.reset_accum()
+    o.render(3, 32, seed=31, nee_mode=0)
+    want = o.read_accum()[0].tobytes()
+    counters = {}
+    try:
+        for waves in (6, 7):
+            g.set_option(ptcore.OPT_WAVES_PER_SIMD, waves)
+            g.reset_accum()
+            g.reset_counters()
+            g.render(3, 32, seed=31, flags=ptcore.RENDER_COUNT)
+            assert g.read_accum()[0].tobytes() == want, waves
+            c = g.counters()
+            counters[waves] = (c["paths"], c["rays_closest"], c["rays_any"], c["node_tests"], c["prim_tests"])
+        assert counters[6] == counters[7]
+        with pytest.raises(Exception):
+            g.set_option(ptcore.OPT_WAVES_PER_SIMD, 8)
+    finally:
+        g.set_option(ptcore.OPT_WAVES_PER_SIMD, 0)
 
 
 @pytest.mark.parametrize("name", list(SCENES))
