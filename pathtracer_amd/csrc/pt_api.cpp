@@ -690,7 +690,9 @@ static int finalize_scene(pt_ctx* c) {
     c->cfg.spill = (unsigned long long*)c->d_spill.p;
     // Node and primitive records beyond what the 256-MB Infinity Cache holds come from HBM, a step then waits longest, and a
     // seventh wave per SIMD hides more than its 8 registers cost (C5 +3.4 %; C3 / C4, whose records fit, -1.4 % / -2.0 %)
-    c->auto_seven = c->d_pairs.bytes + c->d_prim.bytes > (size_t)256 << 20;
+    const size_t record_bytes = (size_t)(S.n_pairs + 1u) * sizeof(PairRecord) +
+                                (size_t)S.n_prims * (c->prim_kind == PRIM_TRIANGLE ? 4u * kTriStride * sizeof(float) : 4u * sizeof(float));
+    c->auto_seven = record_bytes > (size_t)256 << 20;
     c->built = true;
     c->have_cam = false;
     return PT_OK;
